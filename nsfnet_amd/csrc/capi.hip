@@ -1,0 +1,256 @@
+// C ABI (include/nsfnet_pinn.h) over the HIP kernels.  Host-side only: argument
+// checking, workspace carving and launches.  No device allocation happens here.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/nsfnet_pinn.h"
+#include "kernels.h"
+
+static_assert((int)PINN_FLD_COUNT == (int)FLD_COUNT, "field plane enum mismatch");
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "", long b = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return code;
+}
+static int hipfail(int rc, const char* what) {
+  if (rc == -1000) return fail(-22, "%s: unsupported hidden width (code %ld)", what, (long)rc);
+  return fail(rc, "%s: HIP error %ld", what, (long)-rc);
+}
+
+struct pinn_net_s {
+  int n_out, L, H, HP;
+};
+
+struct pinn_plan_s {
+  pinn_net_s net;
+  long n;
+  int streams, ntiles, npad;
+  int grid_f, grid_b, groups;
+  // workspace offsets in bytes
+  size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
+};
+
+static int num_cus() {
+  static int cached = 0;
+  if (cached) return cached;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cached = prop.multiProcessorCount;
+  else
+    cached = 256;   // MI355X
+  return cached;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" {
+
+const char* pinn_last_error(void) { return g_err; }
+int pinn_abi_version(void) { return 1; }
+
+int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out) {
+  if (!out) return fail(-22, "pinn_net_create: null out%s");
+  if (n_out < 1 || n_out > 3) return fail(-22, "pinn_net_create: n_out must be 1..3%s");
+  if (n_hidden_layers < 1 || n_hidden_layers > 64) return fail(-22, "pinn_net_create: hidden layers must be 1..64%s");
+  if (hidden < 1 || hidden > PINN_MAX_HP) return fail(-22, "pinn_net_create: hidden width must be 1..256 (got %s%ld)", "", hidden);
+  pinn_net_s* n = new (std::nothrow) pinn_net_s;
+  if (!n) return fail(-12, "pinn_net_create: out of host memory%s");
+  n->n_out = n_out; n->L = n_hidden_layers; n->H = hidden; n->HP = (hidden + 31) / 32 * 32;
+  *out = n;
+  return 0;
+}
+int pinn_net_destroy(pinn_net_t net) { delete net; return 0; }
+int64_t pinn_net_num_params(pinn_net_t net) { return net ? (int64_t)flat_total(net->H, net->L, net->n_out) : -1; }
+int64_t pinn_net_prep_floats(pinn_net_t net) { return net ? (int64_t)prep_total(net->HP, net->L) : -1; }
+
+int pinn_net_prepare(pinn_net_t net, const float* params, float* prep, void* stream) {
+  if (!net || !params || !prep) return fail(-22, "pinn_net_prepare: null argument%s");
+  int rc = launch_prep(params, prep, net->H, net->HP, net->L, net->n_out, (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_net_prepare") : 0;
+}
+
+int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t* out) {
+  if (!net || !out) return fail(-22, "pinn_plan_create: null argument%s");
+  if (streams != 1 && streams != 4) return fail(-22, "pinn_plan_create: streams must be 1 or 4%s");
+  if (n_points < 1 || n_points > (int64_t)1 << 30) return fail(-22, "pinn_plan_create: bad point count %s%ld", "", (long)n_points);
+  pinn_plan_s* p = new (std::nothrow) pinn_plan_s;
+  if (!p) return fail(-12, "pinn_plan_create: out of host memory%s");
+  p->net = *net;
+  p->n = n_points; p->streams = streams;
+  const int per_tile = streams == 4 ? 32 : 128;
+  p->ntiles = (int)((n_points + per_tile - 1) / per_tile);
+  p->npad = p->ntiles * per_tile;
+  const int HP = net->HP, L = net->L, NW = HP / 32;
+  const int cus = num_cus();
+  auto bpc = [&](size_t lds) {
+    int b = (int)(163840 / lds);
+    int bw = NW >= 8 ? 1 : 8 / NW;
+    if (b > bw) b = bw;
+    return b < 1 ? 1 : b;
+  };
+  p->grid_f = cus * bpc(fwd_lds_bytes(HP));
+  if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
+  p->grid_b = cus * bpc(bwd_lds_bytes(HP, L));
+  if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
+  if (L > 1) {
+    int g = cus * bpc(dw_lds_bytes(HP)) / (L - 1);
+    if (g < 1) g = 1;
+    if (g > p->ntiles) g = p->ntiles;
+    p->groups = g;
+  } else {
+    p->groups = 0;
+  }
+  size_t off = 0;
+  p->off_partials = off; off = align_up(off + (size_t)p->grid_f * PINN_NLOSS * 4, 256);
+  p->off_oadj = off;     off = align_up(off + (size_t)4 * p->npad * 4, 256);
+  p->bytes_fwd = off;
+  p->off_sg = off;       off = align_up(off + (size_t)p->grid_b * sg_total(HP, L) * 4, 256);
+  p->off_slabs = off;    off = align_up(off + (size_t)(L - 1) * p->groups * HP * HP * 4, 256);
+  p->off_S = off;        off = align_up(off + (size_t)p->ntiles * L * act_block(HP) * 4, 256);
+  p->off_Zb = off;       off = align_up(off + (size_t)p->ntiles * L * act_block(HP) * 4, 256);
+  p->bytes_all = off;
+  *out = p;
+  return 0;
+}
+int pinn_plan_destroy(pinn_plan_t plan) { delete plan; return 0; }
+int64_t pinn_plan_padded_points(pinn_plan_t plan) { return plan ? plan->npad : -1; }
+int64_t pinn_plan_workspace_bytes(pinn_plan_t plan, int with_backward) {
+  if (!plan) return -1;
+  return (int64_t)(with_backward ? plan->bytes_all : plan->bytes_fwd);
+}
+
+#define WS(p, off) reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (p)->off)
+
+int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
+                          const float* x, const float* y, const float* e, const float* w,
+                          float* vis_t_minus, float* vis_t_out, float* fields,
+                          float Re, float vis_t0, float alpha_evm, float coord_scale,
+                          int save, float* loss_sums, void* stream) {
+  if (!plan || !ws || !prep || !x || !y || !fields) return fail(-22, "pinn_residual_forward: null argument%s");
+  if (plan->streams != 4) return fail(-22, "pinn_residual_forward: plan is not a residual (4-stream) plan%s");
+  if (!(Re > 0.f)) return fail(-22, "pinn_residual_forward: Re must be > 0%s");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.n = (int)plan->n; a.ntiles = plan->ntiles; a.L = plan->net.L; a.n_out = plan->net.n_out;
+  a.prep = prep; a.S = save ? WS(plan, off_S) : nullptr;
+  a.fld = fields; a.e = e; a.w = w; a.vtm = vis_t_minus; a.vis_used = vis_t_out;
+  a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
+  a.partials = WS(plan, off_partials);
+  int rc = launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
+  if (rc) return hipfail(rc, "pinn_residual_forward");
+  if (loss_sums) {
+    rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
+    if (rc) return hipfail(rc, "pinn_residual_forward(loss sums)");
+  }
+  return 0;
+}
+
+static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
+  DwArgs d;
+  d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
+  d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
+  d.slabs = WS(plan, off_slabs);
+  return launch_dw(plan->net.HP, plan->streams, d, s);
+}
+
+int pinn_residual_backward(pinn_plan_t plan, void* ws, const float* prep,
+                           const float* x, const float* y, const float* e, const float* w,
+                           const float* vis_t, const float* fields, const float* coef_eq4,
+                           float Re, float coord_scale, float* ebar_out, void* stream) {
+  if (!plan || !ws || !prep || !x || !y || !fields || !coef_eq4) return fail(-22, "pinn_residual_backward: null argument%s");
+  if (plan->streams != 4) return fail(-22, "pinn_residual_backward: plan is not a residual (4-stream) plan%s");
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.n = (int)plan->n; a.ntiles = plan->ntiles; a.L = plan->net.L; a.n_out = plan->net.n_out;
+  a.prep = prep; a.S = WS(plan, off_S); a.Zb = WS(plan, off_Zb);
+  a.fld = fields; a.e = e; a.w = w; a.vis_used = vis_t;
+  for (int k = 0; k < 4; ++k) a.coef_eq[k] = coef_eq4[k];
+  a.inv_re = 1.0f / Re; a.scale = coord_scale; a.ebar = ebar_out;
+  a.sg = WS(plan, off_sg);
+  int rc = launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+  if (rc) return hipfail(rc, "pinn_residual_backward");
+  rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_residual_backward(dW)") : 0;
+}
+
+int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
+                       const float* x, const float* y,
+                       float* const* pred3, const float* const* tgt3, const float* coef3,
+                       int save, float* loss_sums, void* stream) {
+  if (!plan || !ws || !prep || !x || !y) return fail(-22, "pinn_value_forward: null argument%s");
+  if (plan->streams != 1) return fail(-22, "pinn_value_forward: plan is not a value (1-stream) plan%s");
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.n = (int)plan->n; a.ntiles = plan->ntiles; a.L = plan->net.L; a.n_out = plan->net.n_out;
+  a.prep = prep; a.S = save ? WS(plan, off_S) : nullptr;
+  for (int c = 0; c < 3; ++c) {
+    a.pred[c] = (pred3 && c < a.n_out) ? pred3[c] : nullptr;
+    a.tgt[c] = (tgt3 && c < a.n_out) ? tgt3[c] : nullptr;
+    a.coef[c] = coef3 ? coef3[c] : 0.f;
+  }
+  a.oadj = save ? WS(plan, off_oadj) : nullptr;
+  a.scale = 1.f;
+  a.partials = WS(plan, off_partials);
+  int rc = launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
+  if (rc) return hipfail(rc, "pinn_value_forward");
+  if (loss_sums) {
+    rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
+    if (rc) return hipfail(rc, "pinn_value_forward(loss sums)");
+  }
+  return 0;
+}
+
+int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
+                        const float* x, const float* y, const float* out_adj, void* stream) {
+  if (!plan || !ws || !prep || !x || !y) return fail(-22, "pinn_value_backward: null argument%s");
+  if (plan->streams != 1) return fail(-22, "pinn_value_backward: plan is not a value (1-stream) plan%s");
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.y = y; a.n = (int)plan->n; a.ntiles = plan->ntiles; a.L = plan->net.L; a.n_out = plan->net.n_out;
+  a.prep = prep; a.S = WS(plan, off_S); a.Zb = WS(plan, off_Zb);
+  a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
+  a.scale = 1.f;
+  a.sg = WS(plan, off_sg);
+  int rc = launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
+  if (rc) return hipfail(rc, "pinn_value_backward");
+  rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;
+}
+
+int pinn_grad_reduce(pinn_net_t net, int nsrc, const pinn_plan_t* plans, void* const* wss,
+                     float* grads, int accumulate, void* stream) {
+  if (!net || !plans || !wss || !grads) return fail(-22, "pinn_grad_reduce: null argument%s");
+  if (nsrc < 1 || nsrc > 4) return fail(-22, "pinn_grad_reduce: nsrc must be 1..4%s");
+  ReduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.nsrc = nsrc; r.H = net->H; r.HP = net->HP; r.L = net->L; r.n_out = net->n_out;
+  r.grads = grads; r.accumulate = accumulate;
+  for (int k = 0; k < nsrc; ++k) {
+    pinn_plan_t p = plans[k];
+    void* ws = wss[k];
+    if (!p || !ws) return fail(-22, "pinn_grad_reduce: null plan/workspace%s");
+    if (p->net.H != net->H || p->net.L != net->L || p->net.n_out != net->n_out)
+      return fail(-22, "pinn_grad_reduce: plan belongs to a different net%s");
+    r.src[k].slabs = WS(p, off_slabs); r.src[k].groups = p->groups;
+    r.src[k].sg = WS(p, off_sg); r.src[k].nwg = p->grid_b;
+  }
+  int rc = launch_reduce(r, (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_grad_reduce") : 0;
+}
+
+int pinn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+  if (!params || !grads || !m || !v) return fail(-22, "pinn_adam_step: null argument%s");
+  if (step < 1) return fail(-22, "pinn_adam_step: step must be >= 1%s");
+  double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  int rc = launch_adam(params, grads, m, v, (long)n, (float)((double)lr / bc1), beta1, beta2, eps, (float)std::sqrt(bc2),
+                       (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_adam_step") : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Internal kernel argument blocks and launchers (gfx950).  Not part of the C ABI;
+// the exported surface is include/nsfnet_pinn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "layout.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Field planes written by the residual forward and read by the backward
+// (plane stride = padded point count).
+enum { FLD_U = 0, FLD_V, FLD_UX, FLD_UY, FLD_VX, FLD_VY, FLD_EQ1, FLD_EQ2, FLD_EQ3, FLD_EQ4, FLD_P, FLD_COUNT };
+
+struct FwdArgs {
+  const float* x; const float* y;
+  int n;            // real points
+  int ntiles;       // tiles of 32 (residual) / 128 (value) points
+  int L;            // hidden layers
+  int n_out;        // 3 (u,v,p) or 1 (e)
+  const float* prep;
+  float* S;         // [tile][L][HP*128] saved (t, z_x, z_y, z_D) or null
+  // residual mode (4 streams)
+  float* fld;       // [FLD_COUNT][npad]
+  const float* e;   // entropy-net output per point or null
+  const float* w;   // per-point weights or null
+  float* vtm;       // vis_t_minus state (in/out) or null
+  float* vis_used;  // artificial viscosity used this step (out) or null
+  float inv_re, vis_t0, alpha_evm, scale;
+  // value mode (1 stream)
+  float* pred[3];        // optional prediction planes
+  const float* tgt[3];   // optional targets (NaN target = masked)
+  float* oadj;           // [4][npad] output adjoints (written when non-null)
+  float coef[3];         // oadj_c = coef[c] * (pred_c - tgt_c)
+  float* partials;       // [grid][PINN_NLOSS]
+};
+
+struct BwdArgs {
+  const float* x; const float* y;
+  int n, ntiles, L, n_out;
+  const float* prep;
+  const float* S;
+  float* Zb;             // [tile][L][HP*128] z-adjoints (layers 1..L-1 used)
+  // residual mode
+  const float* fld; const float* e; const float* w; const float* vis_used;
+  float coef_eq[4];      // 2*alpha_e*c_k/N_total
+  float inv_re, scale;
+  float* ebar;           // d loss / d e per point (out) or null
+  // value mode
+  const float* oadj;     // [4][npad]
+  float* sg;             // [grid][sg_total]
+};
+
+struct DwArgs {
+  const float* S; const float* Zb;
+  int ntiles, L, groups;
+  float* slabs;          // [(L-1)][groups][HP*HP]
+};
+
+struct ReduceSrc { const float* slabs; int groups; const float* sg; int nwg; };
+struct ReduceArgs {
+  ReduceSrc src[4]; int nsrc;
+  int H, HP, L, n_out;
+  float* grads; int accumulate;
+};
+
+int launch_fwd(int HP, int NS, const FwdArgs& a, int grid, hipStream_t s);
+int launch_bwd(int HP, int NS, const BwdArgs& a, int grid, hipStream_t s);
+int launch_dw(int HP, int NS, const DwArgs& a, hipStream_t s);
+size_t fwd_lds_bytes(int HP);
+size_t bwd_lds_bytes(int HP, int L);
+size_t dw_lds_bytes(int HP);
+int dw_threads(int HP);
+
+int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, hipStream_t s);
+int launch_reduce(const ReduceArgs& a, hipStream_t s);
+int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float step_size, float b1, float b2,
+                float eps, float bc2_sqrt, hipStream_t s);

@@ -1,0 +1,152 @@
+// Small bandwidth-bound kernels around the MFMA pipeline: parameter re-layout,
+// fixed-order gradient / loss reductions and the fused Adam update.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------
+// flat state_dict-order parameters (NSFnet/net.py:36-46) -> padded, MFMA-fragment
+// ordered copies (layout.h).  Wf: lane (i = lane&31, h = lane>>5) of wave w holds
+// W[32w+i][2ks+h] for ks = 0..HP/2-1, four ks per 16-byte load.  WTf: same with W^T.
+// ---------------------------------------------------------------------------
+__global__ void prep_kernel(const float* __restrict__ params, float* __restrict__ prep,
+                            int H, int HP, int L, int n_out) {
+  const size_t total = prep_total(HP, L);
+  for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (idx < (size_t)3 * HP) {
+      int which = (int)(idx / HP), o = (int)(idx % HP);
+      if (o < H) v = which == 0 ? params[flat_w(H, 0) + 2 * o] : which == 1 ? params[flat_w(H, 0) + 2 * o + 1]
+                                                                            : params[flat_b(H, 0, L, n_out) + o];
+    } else if (idx < prep_wout(HP, L)) {
+      size_t rel = idx - (size_t)3 * HP;
+      int l = 1 + (int)(rel / prep_layer_stride(HP));
+      size_t q = rel % prep_layer_stride(HP);
+      const float* W = params + flat_w(H, l);
+      if (q < (size_t)2 * HP * HP) {
+        bool tr = q >= (size_t)HP * HP;
+        size_t f = tr ? q - (size_t)HP * HP : q;
+        int e = (int)(f & 3), lane = (int)((f >> 2) & 63);
+        int wq = (int)(f >> 8);
+        int qq = wq % (HP / 8), w = wq / (HP / 8);
+        int k = 2 * (4 * qq + e) + (lane >> 5), o = 32 * w + (lane & 31);
+        if (o < H && k < H) v = tr ? W[(size_t)k * H + o] : W[(size_t)o * H + k];
+      } else {
+        int o = (int)(q - (size_t)2 * HP * HP);
+        if (o < H) v = params[flat_b(H, l, L, n_out) + o];
+      }
+    } else if (idx < prep_bout(HP, L)) {
+      size_t q = idx - prep_wout(HP, L);
+      int c = (int)(q / HP), k = (int)(q % HP);
+      if (c < n_out && k < H) v = params[flat_w(H, L) + (size_t)c * H + k];
+    } else {
+      int c = (int)(idx - prep_bout(HP, L));
+      if (c < n_out) v = params[flat_b(H, L, L, n_out) + c];
+    }
+    prep[idx] = v;
+  }
+}
+
+int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, hipStream_t s) {
+  size_t total = prep_total(HP, L);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, params, prep, H, HP, L, n_out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------
+// gradient assembly: one thread per flat parameter sums that parameter's partials
+// (dW slabs of dw.hip, per-workgroup skinny accumulators of bwd.hip) over all
+// sources in a fixed order, in fp64.
+// ---------------------------------------------------------------------------
+__global__ void reduce_kernel(ReduceArgs a) {
+  const int H = a.H, HP = a.HP, L = a.L;
+  const size_t P = flat_total(H, L, a.n_out);
+  size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  // decode
+  int sgi = -1; int layer = -1; size_t slab_off = 0;
+  if (p < (size_t)2 * H) {
+    int o = (int)(p / 2), j = (int)(p % 2);
+    sgi = (j == 0 ? sg_w0x(HP, L) : sg_w0y(HP, L)) + o;
+  } else if (p < (size_t)3 * H) {
+    sgi = sg_db(HP, 0) + (int)(p - 2 * H);
+  } else if (p < flat_w(H, L)) {
+    size_t rel = p - (size_t)3 * H;
+    size_t per = (size_t)H * H + H;
+    int l = 1 + (int)(rel / per);
+    size_t q = rel % per;
+    if (q < (size_t)H * H) { layer = l; slab_off = (q / H) * HP + (q % H); }
+    else sgi = sg_db(HP, l) + (int)(q - (size_t)H * H);
+  } else {
+    size_t q = p - flat_w(H, L);
+    if (q < (size_t)a.n_out * H) sgi = sg_wout(HP, L) + (int)(q / H) * HP + (int)(q % H);
+    else sgi = sg_bout(HP, L) + (int)(q - (size_t)a.n_out * H);
+  }
+  double s = 0.0;
+  const int SG = sg_total(HP, L);
+  for (int k = 0; k < a.nsrc; ++k) {
+    const ReduceSrc& src = a.src[k];
+    if (layer >= 0) {
+      const float* base = src.slabs + (size_t)(layer - 1) * src.groups * HP * HP + slab_off;
+      for (int g = 0; g < src.groups; ++g) s += (double)base[(size_t)g * HP * HP];
+    } else {
+      for (int g = 0; g < src.nwg; ++g) s += (double)src.sg[(size_t)g * SG + sgi];
+    }
+  }
+  if (a.accumulate) a.grads[p] += (float)s; else a.grads[p] = (float)s;
+}
+
+int launch_reduce(const ReduceArgs& a, hipStream_t s) {
+  size_t P = flat_total(a.H, a.L, a.n_out);
+  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------
+// loss partial sums [nparts][PINN_NLOSS] -> out[PINN_NLOSS] (fp64 accumulate, fixed order)
+// ---------------------------------------------------------------------------
+__global__ void loss_sums_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+  int k = threadIdx.x;
+  if (k >= PINN_NLOSS) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += (double)partials[(size_t)i * PINN_NLOSS + k];
+  out[k] = (float)s;
+}
+
+int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(loss_sums_kernel, dim3(1), dim3(64), 0, s, partials, nparts, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------
+// Adam, torch.optim.Adam single-tensor semantics (weight_decay = 0, amsgrad = False),
+// as used at NSFnet/pinn_solver.py:76-79,253 and ev-NSFnet/pinn_solver.py:126-129,472:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float step_size, float b1, float b2, float eps,
+                            float bc2_sqrt) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = m[i] + (gi - m[i]) * (1.f - b1);           // torch: exp_avg.lerp_(grad, 1-beta1)
+    float vi = v[i] * b2 + (1.f - b2) * gi * gi;           // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, long n, float step_size, float b1, float b2,
+                float eps, float bc2_sqrt, hipStream_t s) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, step_size, b1, b2, eps, bc2_sqrt);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}

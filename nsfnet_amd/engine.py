@@ -1,0 +1,374 @@
+"""Host-side driver of the HIP PINN pipeline (one process = one GPU).
+
+PyTorch is plumbing here: it owns device memory, the stream and (for N > 1 GPUs) the
+RCCL communicator.  All arithmetic of the training step happens in
+lib/libnsfnet_pinn.so through the C ABI of include/nsfnet_pinn.h.
+
+The step implemented is the reference's solve_Adam loop body
+(NSFnet/pinn_solver.py:250-254, ev-NSFnet/pinn_solver.py:456-472):
+loss (BC MSE + PDE residual MSE [+ supervised MSE]) -> d loss/d theta -> Adam.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NLOSS = 8
+FLD = dict(u=0, v=1, u_x=2, u_y=3, v_x=4, v_y=5, eq1=6, eq2=7, eq3=8, eq4=9, p=10)
+FLD_COUNT = 11
+
+# slots of the per-step sums vector (all-reduced together with the gradients)
+S_EQ = 0        # 0..3  sum w*eq_k^2
+S_BC = 4        # 4,5   sum (u-u_b)^2, sum (v-v_b)^2
+S_SUP = 8       # 8..10 sum sq err u,v,p ; 11 = number of finite p targets
+NSUMS = 16
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def layer_shapes(n_out, n_hidden, hidden):
+    widths = [2] + [hidden] * n_hidden + [n_out]
+    return [(widths[i + 1], widths[i]) for i in range(len(widths) - 1)]
+
+
+class DeviceNet:
+    """One FCNet on the device: flat fp32 parameters in reference state_dict order
+    (NSFnet/net.py:36-46) plus their MFMA-fragment-ordered copy."""
+
+    def __init__(self, n_out, n_hidden, hidden, device):
+        self.lib = _lib.load()
+        self.n_out, self.n_hidden, self.hidden, self.device = n_out, n_hidden, hidden, device
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.pinn_net_create(n_out, n_hidden, hidden, ctypes.byref(h)), "pinn_net_create")
+        self.handle = h
+        self.num_params = int(self.lib.pinn_net_num_params(h))
+        self.params = torch.zeros(self.num_params, dtype=torch.float32, device=device)
+        self.prep = torch.zeros(int(self.lib.pinn_net_prep_floats(h)), dtype=torch.float32, device=device)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.adam_t = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pinn_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- state_dict interop (checkpoint format of the reference) ----
+    def keys_and_shapes(self):
+        out = []
+        for i, (o, k) in enumerate(layer_shapes(self.n_out, self.n_hidden, self.hidden)):
+            out.append(("layers.layer_%d.weight" % i, (o, k)))
+            out.append(("layers.layer_%d.bias" % i, (o,)))
+        return out
+
+    def load_state_dict(self, sd):
+        flat = []
+        for key, shape in self.keys_and_shapes():
+            t = sd[key]
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError("state_dict[%s] has shape %s, expected %s" % (key, tuple(t.shape), shape))
+            flat.append(t.detach().to(torch.float32).reshape(-1).cpu())
+        self.set_flat(torch.cat(flat))
+
+    def state_dict(self):
+        sd, off = {}, 0
+        flat = self.params.detach().cpu()
+        for key, shape in self.keys_and_shapes():
+            n = int(np.prod(shape))
+            sd[key] = flat[off:off + n].reshape(shape).clone()
+            off += n
+        return sd
+
+    def set_flat(self, flat):
+        flat = torch.as_tensor(flat, dtype=torch.float32).reshape(-1)
+        if flat.numel() != self.num_params:
+            raise ValueError("expected %d parameters, got %d" % (self.num_params, flat.numel()))
+        self.params.copy_(flat.to(self.device))
+        self.prepare()
+
+    def prepare(self):
+        _lib.check(self.lib.pinn_net_prepare(self.handle, _ptr(self.params), _ptr(self.prep), _stream()),
+                   "pinn_net_prepare")
+
+    def reset_adam(self):
+        self.m.zero_(); self.v.zero_(); self.adam_t = 0
+
+    def adam_step(self, grads, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.adam_t += 1
+        _lib.check(self.lib.pinn_adam_step(_ptr(self.params), _ptr(grads), _ptr(self.m), _ptr(self.v),
+                                           self.num_params, lr, betas[0], betas[1], eps, self.adam_t, _stream()),
+                   "pinn_adam_step")
+        self.prepare()
+
+
+class PointPlan:
+    """A fixed set of points evaluated by one DeviceNet (residual or value mode)."""
+
+    def __init__(self, net, x, y, streams, with_backward=True):
+        self.lib, self.net, self.streams = net.lib, net, streams
+        dev = net.device
+        self.x = torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(-1)).to(dev).contiguous()
+        self.y = torch.as_tensor(np.asarray(y, dtype=np.float32).reshape(-1)).to(dev).contiguous()
+        self.n = self.x.numel()
+        if self.y.numel() != self.n or self.n == 0:
+            raise ValueError("x and y must be non-empty and of equal length")
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.pinn_plan_create(net.handle, self.n, streams, ctypes.byref(h)), "pinn_plan_create")
+        self.handle = h
+        self.npad = int(self.lib.pinn_plan_padded_points(h))
+        self.with_backward = with_backward
+        nbytes = int(self.lib.pinn_plan_workspace_bytes(h, 1 if with_backward else 0))
+        self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        self.sums = torch.zeros(NLOSS, dtype=torch.float32, device=dev)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.pinn_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ResidualPlan(PointPlan):
+    def __init__(self, net, x, y, weights=None, with_backward=True):
+        super().__init__(net, x, y, 4, with_backward)
+        dev = net.device
+        self.fields = torch.zeros(FLD_COUNT, self.npad, dtype=torch.float32, device=dev)
+        self.w = None if weights is None else torch.as_tensor(
+            np.asarray(weights, dtype=np.float32).reshape(-1)).to(dev).contiguous()
+        if self.w is not None and self.w.numel() != self.n:
+            raise ValueError("weights must have one entry per collocation point")
+        self.vis_t = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.vis_t_minus = None     # lagged alpha_evm*|e| state (ev flavour)
+        self.ebar = None
+
+    def forward(self, Re, e=None, vis_t0=0.0, alpha_evm=0.0, scale=1.0, save=True, sums_out=None):
+        if save and not self.with_backward:
+            raise RuntimeError("plan was created without backward workspace")
+        _lib.check(self.lib.pinn_residual_forward(
+            self.handle, _ptr(self.ws), _ptr(self.net.prep), _ptr(self.x), _ptr(self.y), _ptr(e), _ptr(self.w),
+            _ptr(self.vis_t_minus), _ptr(self.vis_t), _ptr(self.fields), float(Re), float(vis_t0),
+            float(alpha_evm), float(scale), 1 if save else 0,
+            _ptr(self.sums if sums_out is None else sums_out), _stream()), "pinn_residual_forward")
+
+    def backward(self, Re, coef_eq, e=None, scale=1.0, want_ebar=False):
+        if want_ebar and self.ebar is None:
+            self.ebar = torch.zeros(((self.n + 127) // 128) * 128, dtype=torch.float32, device=self.net.device)
+        coef = (ctypes.c_float * 4)(*[float(c) for c in coef_eq])
+        _lib.check(self.lib.pinn_residual_backward(
+            self.handle, _ptr(self.ws), _ptr(self.net.prep), _ptr(self.x), _ptr(self.y), _ptr(e), _ptr(self.w),
+            _ptr(self.vis_t), _ptr(self.fields), coef, float(Re), float(scale),
+            _ptr(self.ebar if want_ebar else None), _stream()), "pinn_residual_backward")
+
+    def field(self, name):
+        return self.fields[FLD[name], :self.n]
+
+
+class ValuePlan(PointPlan):
+    def __init__(self, net, x, y, targets=None, with_backward=True):
+        super().__init__(net, x, y, 1, with_backward)
+        dev = net.device
+        self.pred = torch.zeros(net.n_out, self.n, dtype=torch.float32, device=dev)
+        self.targets = [None, None, None]
+        if targets is not None:
+            for c, t in enumerate(targets):
+                if t is not None:
+                    tt = torch.as_tensor(np.asarray(t, dtype=np.float32).reshape(-1)).to(dev).contiguous()
+                    if tt.numel() != self.n:
+                        raise ValueError("target %d must have one entry per point" % c)
+                    self.targets[c] = tt
+
+    def forward(self, coef=(0.0, 0.0, 0.0), save=False, use_targets=True, sums_out=None):
+        if save and not self.with_backward:
+            raise RuntimeError("plan was created without backward workspace")
+        n_out = self.net.n_out
+        pred = (ctypes.c_void_p * 3)(*[self.pred[c].data_ptr() if c < n_out else 0 for c in range(3)])
+        tgt = (ctypes.c_void_p * 3)(*[(self.targets[c].data_ptr() if (use_targets and self.targets[c] is not None) else 0)
+                                      for c in range(3)])
+        cf = (ctypes.c_float * 3)(*[float(c) for c in coef])
+        _lib.check(self.lib.pinn_value_forward(
+            self.handle, _ptr(self.ws), _ptr(self.net.prep), _ptr(self.x), _ptr(self.y), pred, tgt, cf,
+            1 if save else 0, _ptr(self.sums if sums_out is None else sums_out), _stream()), "pinn_value_forward")
+
+    def backward(self, out_adj=None):
+        _lib.check(self.lib.pinn_value_backward(
+            self.handle, _ptr(self.ws), _ptr(self.net.prep), _ptr(self.x), _ptr(self.y), _ptr(out_adj), _stream()),
+            "pinn_value_backward")
+
+
+def grad_reduce(net, plans, grads_out, accumulate=False):
+    lib = net.lib
+    n = len(plans)
+    ph = (ctypes.c_void_p * n)(*[p.handle.value for p in plans])
+    wh = (ctypes.c_void_p * n)(*[p.ws.data_ptr() for p in plans])
+    _lib.check(lib.pinn_grad_reduce(net.handle, n, ph, wh, _ptr(grads_out), 1 if accumulate else 0, _stream()),
+               "pinn_grad_reduce")
+
+
+class PinnEngine:
+    """The per-step hot path for one rank.
+
+    flavour 'nsfnet': loss = alpha_b*loss_b + alpha_e*(m(eq1)+m(eq2)+m(eq3)), nu = 1/Re
+                      (NSFnet/pinn_solver.py:197-226)
+    flavour 'ev':     adds the entropy net e, lagged artificial viscosity, eq4 with weight
+                      0.1, SDF weights, optional supervised loss
+                      (ev-NSFnet/pinn_solver.py:290-342, 372-428)
+    Multi-GPU: every rank holds a shard of the points; ONE all-reduce (RCCL) of
+    [grad | grad_e | sums] per step, all normalisations use GLOBAL counts.
+    """
+
+    def __init__(self, device, n_hidden, hidden, Re, alpha_b=1.0, alpha_e=1.0, flavour="nsfnet",
+                 n_hidden_e=None, hidden_e=None, alpha_evm=0.0, alpha_s=0.0, coord_scale=1.0,
+                 vis_t0_factor=20.0, process_group=None, world_size=1):
+        self.device = torch.device(device)
+        self.flavour = flavour
+        self.Re = float(Re)
+        self.alpha_b, self.alpha_e, self.alpha_s = float(alpha_b), float(alpha_e), float(alpha_s)
+        self.alpha_evm = float(alpha_evm)
+        self.scale = float(coord_scale)
+        self.vis_t0 = vis_t0_factor / self.Re
+        self.net = DeviceNet(3, n_hidden, hidden, self.device)
+        self.net_e = DeviceNet(1, n_hidden_e, hidden_e, self.device) if flavour == "ev" else None
+        self.e_trainable = False
+        self.pg, self.world_size = process_group, int(world_size)
+        P = self.net.num_params + (self.net_e.num_params if self.net_e else 0)
+        self.flat = torch.zeros(P + NSUMS, dtype=torch.float32, device=self.device)
+        self.P, self.P1 = self.net.num_params, (self.net_e.num_params if self.net_e else 0)
+        self.plan_f = self.plan_b = self.plan_s = self.plan_e = None
+        self.n_f_global = self.n_b_global = self.n_s_global = 0
+        self.eq4_weight = 0.1
+
+    # ---- views into the exchange buffer ----
+    @property
+    def grads(self):
+        return self.flat[:self.P]
+
+    @property
+    def grads_e(self):
+        return self.flat[self.P:self.P + self.P1]
+
+    @property
+    def sums(self):
+        return self.flat[self.P + self.P1:]
+
+    # ---- data ----
+    def set_collocation(self, x, y, weights=None, n_global=None):
+        self.plan_f = ResidualPlan(self.net, x, y, weights)
+        self.n_f_global = int(n_global if n_global is not None else self.plan_f.n)
+        if self.net_e is not None:
+            self.plan_e = ValuePlan(self.net_e, x, y)
+            self.init_vis_t()
+
+    def set_boundary(self, x, y, u, v, n_global=None):
+        self.plan_b = ValuePlan(self.net, x, y, targets=[u, v, None])
+        self.n_b_global = int(n_global if n_global is not None else self.plan_b.n)
+
+    def set_supervised(self, x, y, u, v, p=None, n_global=None):
+        if x is None:
+            self.plan_s, self.n_s_global = None, 0
+            return
+        self.plan_s = ValuePlan(self.net, x, y, targets=[u, v, p])
+        self.n_s_global = int(n_global if n_global is not None else self.plan_s.n)
+
+    def init_vis_t(self):
+        """vis_t_minus = alpha_evm*|e(x_f)|   (ev-NSFnet/pinn_solver.py:138-140)"""
+        self.plan_e.forward(save=False)
+        self.plan_f.vis_t_minus = (self.alpha_evm * self.plan_e.pred[0].abs()).contiguous()
+
+    # ---- one loss + gradient evaluation ----
+    def loss_and_grad(self):
+        f, b = self.plan_f, self.plan_b
+        sums = self.sums
+        sums.zero_()
+        e = None
+        if self.net_e is not None:
+            self.plan_e.forward(save=self.e_trainable)
+            e = self.plan_e.pred[0]
+        f.forward(self.Re, e=e, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
+                  sums_out=sums[S_EQ:S_EQ + NLOSS])
+        cb = 2.0 * self.alpha_b / self.n_b_global
+        b.forward(coef=(cb, cb, 0.0), save=True)
+        sums[S_BC:S_BC + 2].copy_(b.sums[0:2])
+        plans = [f, b]
+        s = self.plan_s
+        if s is not None and self.alpha_s != 0.0:
+            # per-output means: u,v over all supervised points, p over its finite targets (ev:399-411)
+            cs = 2.0 * self.alpha_s / self.n_s_global
+            n_p = self._n_p_valid_global()
+            s.forward(coef=(cs, cs, (2.0 * self.alpha_s / n_p) if n_p > 0 else 0.0), save=True)
+            sums[S_SUP:S_SUP + 4].copy_(s.sums[0:4])
+            plans.append(s)
+        c = 2.0 * self.alpha_e / self.n_f_global
+        coef_eq = (c, c, c, c * self.eq4_weight if self.net_e is not None else 0.0)
+        f.backward(self.Re, coef_eq, e=e, scale=self.scale, want_ebar=self.e_trainable)
+        b.backward()
+        if len(plans) == 3:
+            s.backward()
+        grad_reduce(self.net, plans, self.grads)
+        if self.net_e is not None:
+            if self.e_trainable:
+                self.plan_e.backward(out_adj=f.ebar)
+                grad_reduce(self.net_e, [self.plan_e], self.grads_e)
+            else:
+                self.grads_e.zero_()
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.flat, group=self.pg)
+
+    def _n_p_valid_global(self):
+        if getattr(self, "_n_p_valid", None) is None:
+            t = self.plan_s.targets[2]
+            n = 0 if t is None else int(torch.isfinite(t).sum().item())
+            if self.world_size > 1:
+                tt = torch.tensor([n], dtype=torch.int64, device=self.device)
+                torch.distributed.all_reduce(tt, group=self.pg)
+                n = int(tt.item())
+            self._n_p_valid = n
+        return self._n_p_valid
+
+    def loss_terms(self):
+        """Device tensors (no sync): dict of loss_eq1..4, loss_e, loss_b, loss_s, loss."""
+        s = self.sums
+        eq = s[S_EQ:S_EQ + 4] / self.n_f_global
+        loss_e = eq[0] + eq[1] + eq[2] + (self.eq4_weight * eq[3] if self.net_e is not None else 0.0)
+        loss_b = (s[S_BC] + s[S_BC + 1]) / self.n_b_global
+        out = dict(loss_eq1=eq[0], loss_eq2=eq[1], loss_eq3=eq[2], loss_eq4=eq[3], loss_e=loss_e, loss_b=loss_b)
+        loss_s = torch.zeros((), device=self.device)
+        if self.plan_s is not None and self.alpha_s != 0.0:
+            n_p = self._n_p_valid_global()
+            loss_s = (s[S_SUP] + s[S_SUP + 1]) / self.n_s_global + (s[S_SUP + 2] / n_p if n_p > 0 else 0.0)
+        out["loss_s"] = loss_s
+        out["loss"] = self.alpha_b * loss_b + self.alpha_e * loss_e + self.alpha_s * loss_s
+        return out
+
+    def adam_step(self, lr):
+        self.net.adam_step(self.grads, lr)
+        if self.net_e is not None and self.e_trainable:
+            self.net_e.adam_step(self.grads_e, lr)
+
+    def step(self, lr):
+        self.loss_and_grad()
+        self.adam_step(lr)
+
+    # ---- inference (evaluate / test / predict) ----
+    def predict(self, x, y, with_e=False):
+        plan = ValuePlan(self.net, x, y, with_backward=False)
+        plan.forward(save=False)
+        out = [plan.pred[0], plan.pred[1], plan.pred[2]]
+        if with_e and self.net_e is not None:
+            pe = ValuePlan(self.net_e, x, y, with_backward=False)
+            pe.forward(save=False)
+            out.append(pe.pred[0])
+        return out

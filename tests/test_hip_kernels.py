@@ -1,0 +1,142 @@
+"""GPU parity of the HIP pipeline (through the C ABI) against the fp64 forward-mode
+oracle on seeded inputs.  Tolerances (fp32 arithmetic):
+  fields / residuals  max-abs error <= 2e-5 * max|ref|   (noise floor ~2-6e-6)
+  loss sums           relative <= 1e-5
+  gradients           relative L2 <= 1e-4 (measured ~1e-6)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as ar
+from oracle import fwdmode_ref as fr
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine_mod():
+    from nsfnet_amd import engine
+    return engine
+
+
+def _rel_max(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _rand_params(n_out, L, H, seed):
+    net = ar.seeded_net(n_out, L, H, seed=seed)
+    return ar.flat_params(net).numpy().copy()
+
+
+CASES = [  # (L, H, N, Nb)   H=50 / 40 exercise the zero padding to 64, N not a tile multiple
+    (1, 8, 37, 5), (2, 16, 300, 33), (4, 50, 1000, 129), (3, 96, 257, 64), (6, 128, 520, 200), (6, 256, 320, 100),
+    (3, 200, 96, 40),
+]
+
+
+@pytest.mark.parametrize("L,H,N,Nb", CASES)
+def test_residual_and_bc_gradients(L, H, N, Nb):
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    Re, alpha_b, alpha_e = 400.0, 10.0, 1.0
+    flat = _rand_params(3, L, H, seed=100 + H)
+    rng = np.random.RandomState(H + L)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[:: max(1, 2052 // Nb)][:Nb].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=alpha_b, alpha_e=alpha_e)
+    E.net.set_flat(torch.tensor(flat))
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re, alpha_e=alpha_e)
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=alpha_b)
+    out = r["out"]
+    f = E.plan_f
+    for name, ref in (("u", out[:, 0, 0]), ("v", out[:, 1, 0]), ("p", out[:, 2, 0]), ("u_x", out[:, 0, 1]),
+                      ("u_y", out[:, 0, 2]), ("v_x", out[:, 1, 1]), ("v_y", out[:, 1, 2]),
+                      ("eq1", r["eqs"][0]), ("eq2", r["eqs"][1]), ("eq3", r["eqs"][2])):
+        assert _rel_max(f.field(name).cpu().numpy(), ref) < 2e-5, name
+    sums = E.sums.cpu().numpy()
+    np.testing.assert_allclose(sums[0:3], r["sums"], rtol=1e-5)
+    np.testing.assert_allclose(sums[4:6], b["sums"], rtol=1e-5)
+    np.testing.assert_allclose(E.plan_b.pred.cpu().numpy()[:2].T, b["pred"][:, :2], rtol=0, atol=2e-6)
+    g = E.grads.cpu().numpy()
+    assert _rel_l2(g, r["grad"] + b["grad"]) < 1e-4
+    lt = E.loss_terms()
+    ref_loss = alpha_b * sum(b["sums"]) / Nb + alpha_e * sum(r["sums"]) / N
+    assert abs(float(lt["loss"]) - ref_loss) < 1e-5 * ref_loss
+
+
+def test_ev_residuals_weights_scale_and_entropy_gradient():
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    L, H, L1, H1, N, Re = 4, 50, 4, 40, 777, 4000.0
+    flat = _rand_params(3, L, H, seed=5); flat_e = _rand_params(1, L1, H1, seed=6)
+    rng = np.random.RandomState(3)
+    x = (rng.rand(N) * 2 - 1).astype(np.float32); y = (rng.rand(N) * 2 - 1).astype(np.float32)
+    w = (0.3 + rng.rand(N)).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, flavour="ev", n_hidden_e=L1, hidden_e=H1,
+                       alpha_evm=0.05, coord_scale=2.0)
+    E.net.set_flat(torch.tensor(flat)); E.net_e.set_flat(torch.tensor(flat_e))
+    E.e_trainable = True
+    E.set_collocation(x, y, weights=w)
+    E.set_boundary(xb, yb, ub, vb)
+    vtm0 = E.plan_f.vis_t_minus.cpu().numpy().astype(np.float64)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    Pe = fr.unflatten(flat_e.astype(np.float64), 2, 1, L1, H1)
+    e, saved_e = fr.forward1(Pe, x.astype(np.float64), y.astype(np.float64))
+    np.testing.assert_allclose(vtm0, 0.05 * np.abs(e[:, 0]), rtol=1e-4, atol=1e-8)
+    vis_t = np.minimum(np.float32(20.0 / Re), vtm0)
+    np.testing.assert_allclose(E.plan_f.vis_t.cpu().numpy(), vis_t, rtol=1e-6)
+    np.testing.assert_allclose(E.plan_f.vis_t_minus.cpu().numpy(), 0.05 * np.abs(e[:, 0]), rtol=1e-4, atol=1e-8)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re, alpha_e=1.0, vis_t=vis_t,
+                             e=e[:, 0], w=w.astype(np.float64), scale=2.0)
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    for k, name in enumerate(("eq1", "eq2", "eq3", "eq4")):
+        assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < 2e-5, name
+    np.testing.assert_allclose(E.sums.cpu().numpy()[0:4], r["sums"], rtol=1e-5)
+    assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
+    ge = fr.backward1(Pe, x.astype(np.float64), y.astype(np.float64), saved_e, r["e_adj"].reshape(-1, 1))
+    assert _rel_l2(E.grads_e.cpu().numpy(), ge) < 1e-4
+
+
+def test_adam_matches_torch():
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    net = eng.DeviceNet(3, 2, 16, dev)
+    torch.manual_seed(0)
+    p0 = torch.randn(net.num_params)
+    net.set_flat(p0)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    for k in range(5):
+        g = torch.randn(net.num_params) * (10.0 ** (-k))
+        ref.grad = g.clone()
+        opt.step()
+        net.adam_step(g.to(dev), 1e-3)
+        np.testing.assert_allclose(net.params.cpu().numpy(), ref.detach().numpy(), rtol=2e-6, atol=1e-8)
+
+
+def test_predict_matches_forward1():
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    L, H = 6, 256
+    flat = _rand_params(3, L, H, seed=1234)
+    E = eng.PinnEngine(dev, L, H, 2000.0)
+    E.net.set_flat(torch.tensor(flat))
+    x, y = ar.uniform_grid(33, 21)
+    u, v, p = E.predict(x.astype(np.float32), y.astype(np.float32))
+    out, _ = fr.forward1(fr.unflatten(flat.astype(np.float64), 2, 3, L, H), x.astype(np.float32), y.astype(np.float32))
+    for mine, ref in ((u, out[:, 0]), (v, out[:, 1]), (p, out[:, 2])):
+        np.testing.assert_allclose(mine.cpu().numpy(), ref, rtol=0, atol=3e-6)
