@@ -79,16 +79,25 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
  * Replaces loss.backward() for the PDE loss (NSFnet/pinn_solver.py:252; ev:469):
  * d/dtheta of sum_k coef_eq[k]/2 * sum_i w_i eq_k,i^2, i.e. the caller passes
  * coef_eq[k] = 2*alpha_e*c_k/N_global (c = 1,1,1,0.1).  Partial gradients stay in `ws`
- * until pinn_grad_reduce.  ebar_out [n] (or NULL) receives d loss/d e. */
+ * until pinn_grad_reduce.  ebar_out [n] (or NULL) receives d loss/d e.
+ * coef_eq4 is a HOST array of 4 floats. */
 int pinn_residual_backward(pinn_plan_t plan, void* ws, const float* prep,
                            const float* x, const float* y, const float* e, const float* w,
                            const float* vis_t, const float* fields, const float* coef_eq4,
                            float Re, float coord_scale, float* ebar_out, void* stream);
 
+/* Same, restricted to phases (bit 0: adjoint sweep that spills the z-adjoints, bit 1:
+ * weight-gradient GEMM); for per-kernel timing in bench.py.  phases = 3 is the call above. */
+int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
+                                  const float* x, const float* y, const float* e, const float* w,
+                                  const float* vis_t, const float* fields, const float* coef_eq4,
+                                  float Re, float coord_scale, float* ebar_out, int phases, void* stream);
+
 /* ---- value forward / backward -----------------------------------------------
  * Replaces neural_net_u and the boundary / supervised MSE terms
  * (NSFnet/pinn_solver.py:124-130,199-207; ev:280-288,374-379,399-411) and, with
  * save = 0, the inference forward of evaluate/test (NSFnet/pinn_solver.py:308-357).
+ *   pred3/tgt3/coef3 are HOST arrays of 3 entries (device pointers / floats):
  *   pred[c]  [n] out planes or NULL ; tgt[c] [n] targets or NULL (NaN target = masked)
  *   coef[c]  output adjoint scale: oadj_c = coef[c]*(pred_c - tgt_c), kept in ws
  *   loss_sums slots 0..2 = sum (pred_c - tgt_c)^2 over valid targets, slot 3 = number

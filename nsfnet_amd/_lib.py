@@ -27,6 +27,9 @@ SIGNATURES = {
     "pinn_residual_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_float,
                                        c_void_p, c_void_p]),
+    "pinn_residual_backward_phases": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, ctypes.POINTER(c_float), c_float, c_float,
+                                              c_void_p, c_int, c_void_p]),
     "pinn_value_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_float),
                                    c_int, c_void_p, c_void_p]),

@@ -157,10 +157,10 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   return launch_dw(plan->net.HP, plan->streams, d, s);
 }
 
-int pinn_residual_backward(pinn_plan_t plan, void* ws, const float* prep,
-                           const float* x, const float* y, const float* e, const float* w,
-                           const float* vis_t, const float* fields, const float* coef_eq4,
-                           float Re, float coord_scale, float* ebar_out, void* stream) {
+int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
+                                  const float* x, const float* y, const float* e, const float* w,
+                                  const float* vis_t, const float* fields, const float* coef_eq4,
+                                  float Re, float coord_scale, float* ebar_out, int phases, void* stream) {
   if (!plan || !ws || !prep || !x || !y || !fields || !coef_eq4) return fail(-22, "pinn_residual_backward: null argument%s");
   if (plan->streams != 4) return fail(-22, "pinn_residual_backward: plan is not a residual (4-stream) plan%s");
   BwdArgs a;
@@ -171,10 +171,21 @@ int pinn_residual_backward(pinn_plan_t plan, void* ws, const float* prep,
   for (int k = 0; k < 4; ++k) a.coef_eq[k] = coef_eq4[k];
   a.inv_re = 1.0f / Re; a.scale = coord_scale; a.ebar = ebar_out;
   a.sg = WS(plan, off_sg);
-  int rc = launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
-  if (rc) return hipfail(rc, "pinn_residual_backward");
-  rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
+  int rc = 0;
+  if (phases & 1) {
+    rc = launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+    if (rc) return hipfail(rc, "pinn_residual_backward");
+  }
+  if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_residual_backward(dW)") : 0;
+}
+
+int pinn_residual_backward(pinn_plan_t plan, void* ws, const float* prep,
+                           const float* x, const float* y, const float* e, const float* w,
+                           const float* vis_t, const float* fields, const float* coef_eq4,
+                           float Re, float coord_scale, float* ebar_out, void* stream) {
+  return pinn_residual_backward_phases(plan, ws, prep, x, y, e, w, vis_t, fields, coef_eq4, Re, coord_scale,
+                                       ebar_out, 3, stream);
 }
 
 int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,

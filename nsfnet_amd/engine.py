@@ -164,14 +164,14 @@ class ResidualPlan(PointPlan):
             float(alpha_evm), float(scale), 1 if save else 0,
             _ptr(self.sums if sums_out is None else sums_out), _stream()), "pinn_residual_forward")
 
-    def backward(self, Re, coef_eq, e=None, scale=1.0, want_ebar=False):
+    def backward(self, Re, coef_eq, e=None, scale=1.0, want_ebar=False, phases=3):
         if want_ebar and self.ebar is None:
             self.ebar = torch.zeros(((self.n + 127) // 128) * 128, dtype=torch.float32, device=self.net.device)
         coef = (ctypes.c_float * 4)(*[float(c) for c in coef_eq])
-        _lib.check(self.lib.pinn_residual_backward(
+        _lib.check(self.lib.pinn_residual_backward_phases(
             self.handle, _ptr(self.ws), _ptr(self.net.prep), _ptr(self.x), _ptr(self.y), _ptr(e), _ptr(self.w),
             _ptr(self.vis_t), _ptr(self.fields), coef, float(Re), float(scale),
-            _ptr(self.ebar if want_ebar else None), _stream()), "pinn_residual_backward")
+            _ptr(self.ebar if want_ebar else None), int(phases), _stream()), "pinn_residual_backward")
 
     def field(self, name):
         return self.fields[FLD[name], :self.n]
@@ -232,7 +232,7 @@ class PinnEngine:
 
     def __init__(self, device, n_hidden, hidden, Re, alpha_b=1.0, alpha_e=1.0, flavour="nsfnet",
                  n_hidden_e=None, hidden_e=None, alpha_evm=0.0, alpha_s=0.0, coord_scale=1.0,
-                 vis_t0_factor=20.0, process_group=None, world_size=1):
+                 vis_t0_factor=20.0, process_group=None, world_size=1, net=None, net_e=None):
         self.device = torch.device(device)
         self.flavour = flavour
         self.Re = float(Re)
@@ -240,8 +240,11 @@ class PinnEngine:
         self.alpha_evm = float(alpha_evm)
         self.scale = float(coord_scale)
         self.vis_t0 = vis_t0_factor / self.Re
-        self.net = DeviceNet(3, n_hidden, hidden, self.device)
-        self.net_e = DeviceNet(1, n_hidden_e, hidden_e, self.device) if flavour == "ev" else None
+        self.net = net if net is not None else DeviceNet(3, n_hidden, hidden, self.device)
+        if flavour == "ev":
+            self.net_e = net_e if net_e is not None else DeviceNet(1, n_hidden_e, hidden_e, self.device)
+        else:
+            self.net_e = None
         self.e_trainable = False
         self.pg, self.world_size = process_group, int(world_size)
         P = self.net.num_params + (self.net_e.num_params if self.net_e else 0)
