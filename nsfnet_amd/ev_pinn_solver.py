@@ -289,10 +289,7 @@ class PysicsInformedNeuralNetwork:
         fused = getattr(loss_func, "__func__", None) is PysicsInformedNeuralNetwork.fwd_computing_loss_2d
         for epoch_id in range(num_epoch):
             self.global_step += 1
-            if epoch_id != 0 and epoch_id % 10000 == 0:
-                self.defreeze_evm_net(epoch_id)
-            if (epoch_id - 1) % 10000 == 0:
-                self.freeze_evm_net(epoch_id)
+            self._apply_freeze_schedule(epoch_id)
             interval = self.log_interval if self.log_interval > 0 else 100
             log_now = self.rank == 0 and (epoch_id == 0 or (epoch_id + 1) % interval == 0 or epoch_id == num_epoch - 1)
             save_now = self.rank == 0 and (epoch_id == 0 or epoch_id % 10000 == 0)
@@ -310,6 +307,13 @@ class PysicsInformedNeuralNetwork:
                           N_f=self.N_f)
         if num_epoch > 0:
             self._publish_terms()
+
+    def _apply_freeze_schedule(self, epoch_id):
+        """:459-462 - unfreeze at k*10000 (k >= 1), re-freeze one step later."""
+        if epoch_id != 0 and epoch_id % 10000 == 0:
+            self.defreeze_evm_net(epoch_id)
+        if (epoch_id - 1) % 10000 == 0:
+            self.freeze_evm_net(epoch_id)
 
     def freeze_evm_net(self, epoch_id):
         """:489-499 - entropy net frozen, fresh Adam over the main net."""
