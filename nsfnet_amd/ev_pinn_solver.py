@@ -369,9 +369,12 @@ class PysicsInformedNeuralNetwork:
             h, m = divmod(m, 60)
             return f"{int(h)}h{int(m)}m"
 
-        mem_alloc = torch.cuda.memory_allocated(self.device) / 1024**2
-        mem_reserved = torch.cuda.memory_reserved(self.device) / 1024**2
-        mem_total = torch.cuda.get_device_properties(self.device).total_memory / 1024**2
+        try:
+            mem_alloc = torch.cuda.memory_allocated(self.device) / 1024**2
+            mem_reserved = torch.cuda.memory_reserved(self.device) / 1024**2
+            mem_total = torch.cuda.get_device_properties(self.device).total_memory / 1024**2
+        except Exception:
+            mem_alloc = mem_reserved = mem_total = float('nan')
         pts = (self.x_f.shape[0] if self.x_f is not None else 0) + (self.x_b.shape[0] if self.x_b is not None else 0)
         throughput = interval_it_s * pts
         print(f"[{self.current_stage}] {epoch_id+1:>7d}/{num_epoch:<7d} {progress*100:6.2f}% |{bar}|")

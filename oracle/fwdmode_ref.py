@@ -159,7 +159,7 @@ def residuals(out, Re, vis_t=None, e=None, scale=1.0):
 
 
 def pde_loss_and_grad(params, x, y, Re, alpha_e=1.0, vis_t=None, e=None, w=None,
-                      scale=1.0, n_total=None, eq4_weight=0.1):
+                      scale=1.0, n_total=None, eq4_weight=0.1, coef_eq=None):
     """alpha_e * sum_k c_k mean(w eq_k^2) and its parameter gradient.
     Also returns d(loss)/d(e) per point (seed of the entropy-net backward).
     n_total: global point count when this rank holds a shard (defaults to N)."""
@@ -170,7 +170,10 @@ def pde_loss_and_grad(params, x, y, Re, alpha_e=1.0, vis_t=None, e=None, w=None,
     ww = np.ones(N) if w is None else np.asarray(w).reshape(-1)
     c = [1.0, 1.0, 1.0, eq4_weight]
     sums = [float(np.sum(ww * q * q)) for q in eqs]
-    g = [2.0 * alpha_e * c[k] * ww * eqs[k] / nt for k in range(len(eqs))]
+    if coef_eq is not None:      # explicit d loss / d(sum w eq_k^2 / 2) factors (what the C ABI takes)
+        g = [coef_eq[k] * ww * eqs[k] for k in range(len(eqs))]
+    else:
+        g = [2.0 * alpha_e * c[k] * ww * eqs[k] / nt for k in range(len(eqs))]
     u, v = out[:, 0, 0], out[:, 1, 0]
     s, s2 = scale, scale * scale
     u_x, u_y = out[:, 0, 1] * s, out[:, 0, 2] * s

@@ -1,0 +1,91 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds, loads and exports every
+symbol include/nsfnet_pinn.h declares; host-only entry points validate their arguments;
+the Python side fails loudly when the library is missing (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from oracle import fwdmode_ref as fr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nsfnet_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "nsfnet_pinn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pinn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from nsfnet_amd import _lib
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_host_only_entry_points(lib):
+    assert lib.pinn_abi_version() == 1
+    h = ctypes.c_void_p()
+    assert lib.pinn_net_create(3, 6, 256, ctypes.byref(h)) == 0
+    assert lib.pinn_net_num_params(h) == fr.param_count(2, 3, 6, 256) == 330499
+    assert lib.pinn_net_prep_floats(h) > 2 * 5 * 256 * 256
+    p = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p)) == 0
+    assert lib.pinn_plan_padded_points(p) == 360000
+    assert lib.pinn_plan_workspace_bytes(p, 1) > lib.pinn_plan_workspace_bytes(p, 0) > 0
+    q = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 2052, 1, ctypes.byref(q)) == 0
+    assert lib.pinn_plan_padded_points(q) == 2176          # 17 tiles of 128
+    for handle in (p, q):
+        assert lib.pinn_plan_destroy(handle) == 0
+    assert lib.pinn_net_destroy(h) == 0
+    for n_out, L, H in ((3, 4, 50), (1, 4, 40), (3, 1, 7)):
+        assert lib.pinn_net_create(n_out, L, H, ctypes.byref(h)) == 0
+        assert lib.pinn_net_num_params(h) == fr.param_count(2, n_out, L, H)
+        lib.pinn_net_destroy(h)
+
+
+def test_argument_errors_are_reported(lib):
+    h = ctypes.c_void_p()
+    assert lib.pinn_net_create(3, 6, 400, ctypes.byref(h)) < 0
+    assert b"hidden width" in lib.pinn_last_error()
+    assert lib.pinn_net_create(4, 6, 64, ctypes.byref(h)) < 0
+    assert lib.pinn_net_create(3, 0, 64, ctypes.byref(h)) < 0
+    assert lib.pinn_net_create(3, 2, 16, ctypes.byref(h)) == 0
+    p = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 100, 2, ctypes.byref(p)) < 0
+    assert lib.pinn_plan_create(h, 0, 4, ctypes.byref(p)) < 0
+    assert lib.pinn_plan_create(h, 100, 1, ctypes.byref(p)) == 0
+    # a value plan is refused by the residual entry point before anything is launched
+    rc = lib.pinn_residual_forward(p, 1, 1, 1, 1, None, None, None, None, 1, 100.0, 0.0, 0.0, 1.0, 0, None, None)
+    assert rc < 0 and b"not a residual" in lib.pinn_last_error()
+    assert lib.pinn_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, None) < 0
+    lib.pinn_plan_destroy(p); lib.pinn_net_destroy(h)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from nsfnet_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.PinnLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_path_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "nsfnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
