@@ -1,0 +1,100 @@
+"""BASELINE-size (6x256 net, 360 000 collocation points) checks on the GPU through
+size-independent properties - the fp64 oracle cannot run the whole set in seconds:
+  * pointwise: residuals of a random sample of points (incl. the last tile) equal the
+    oracle's (points are independent);
+  * shard additivity: gradients / loss sums of two half shards normalised by the GLOBAL
+    count add up to the full-batch result (this is the multi-GPU contract);
+  * permutation invariance of loss and gradient;
+  * forward/backward consistency: a central finite difference of the forward loss along a
+    random direction equals grad . direction.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as ar
+from oracle import fwdmode_ref as fr
+
+pytestmark = pytest.mark.gpu
+
+L, H, RE, GRID = 6, 256, 2000.0, 600
+
+
+def _setup(x, y, n_global=None, flat=None):
+    from nsfnet_amd import engine as eng
+    E = eng.PinnEngine(torch.device("cuda:0"), L, H, RE, alpha_b=10.0, alpha_e=1.0)
+    E.net.set_flat(torch.tensor(flat))
+    E.set_collocation(x, y, n_global=n_global)
+    xb, yb, ub, vb = (a.reshape(-1).astype(np.float32) for a in ar.cavity_boundary())
+    E.set_boundary(xb, yb, ub, vb)
+    return E
+
+
+@pytest.fixture(scope="module")
+def base():
+    flat = ar.flat_params(ar.seeded_net(3, L, H, seed=1234)).numpy().copy()
+    x, y = (a.reshape(-1).astype(np.float32) for a in ar.uniform_grid(GRID, GRID))
+    E = _setup(x, y, flat=flat)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    return dict(flat=flat, x=x, y=y, E=E, grads=E.grads.cpu().numpy().astype(np.float64),
+                sums=E.sums.cpu().numpy().astype(np.float64), loss=float(E.loss_terms()["loss"]))
+
+
+def _rel_l2(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_sampled_points_match_oracle(base):
+    rng = np.random.RandomState(0)
+    n = base["x"].size
+    idx = np.unique(np.concatenate([rng.randint(0, n, 300), np.arange(n - 40, n), np.arange(0, 40)]))
+    P = fr.unflatten(base["flat"].astype(np.float64), 2, 3, L, H)
+    out, _ = fr.forward4(P, base["x"][idx].astype(np.float64), base["y"][idx].astype(np.float64))
+    eqs = fr.residuals(out, RE)
+    f = base["E"].plan_f
+    for k, name in enumerate(("eq1", "eq2", "eq3")):
+        mine = f.field(name).cpu().numpy()[idx]
+        assert np.abs(mine - eqs[k]).max() < 2e-5 * np.abs(eqs[k]).max(), name
+    np.testing.assert_allclose(f.field("u").cpu().numpy()[idx], out[:, 0, 0], atol=3e-6)
+
+
+def test_shard_additivity(base):
+    n = base["x"].size
+    half = n // 2
+    g, s = np.zeros_like(base["grads"]), np.zeros(4)
+    for lo, hi in ((0, half), (half, n)):
+        E = _setup(base["x"][lo:hi], base["y"][lo:hi], n_global=n, flat=base["flat"])
+        E.n_b_global = 2 * 2052            # each shard sees the whole BC set here: halve its weight
+        E.loss_and_grad()
+        g += E.grads.cpu().numpy().astype(np.float64)
+        s += E.sums.cpu().numpy().astype(np.float64)[:4]
+        del E
+        torch.cuda.empty_cache()
+    np.testing.assert_allclose(s[:3], base["sums"][:3], rtol=2e-6)
+    assert _rel_l2(g, base["grads"]) < 1e-5
+
+
+def test_permutation_invariance(base):
+    perm = np.random.RandomState(1).permutation(base["x"].size)
+    E = _setup(base["x"][perm], base["y"][perm], flat=base["flat"])
+    E.loss_and_grad()
+    np.testing.assert_allclose(E.sums.cpu().numpy()[:3], base["sums"][:3], rtol=2e-6)
+    assert _rel_l2(E.grads.cpu().numpy().astype(np.float64), base["grads"]) < 1e-5
+
+
+def test_directional_derivative(base):
+    rng = np.random.RandomState(2)
+    d = rng.choice([-1.0, 1.0], size=base["flat"].size)
+    eps = 2e-4
+    E = base["E"]
+    vals = []
+    for sgn in (+1.0, -1.0):
+        E.net.set_flat(torch.tensor((base["flat"].astype(np.float64) + sgn * eps * d).astype(np.float32)))
+        E.loss_and_grad()
+        s = E.sums.cpu().numpy().astype(np.float64)
+        vals.append(10.0 * (s[4] + s[5]) / 2052 + (s[0] + s[1] + s[2]) / base["x"].size)
+    E.net.set_flat(torch.tensor(base["flat"]))
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    gd = float(base["grads"] @ d)
+    assert abs(fd - gd) < 2e-2 * abs(gd), (fd, gd)
