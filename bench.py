@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--grid", type=int, default=600, help="per-GPU collocation grid is grid x grid")
     ap.add_argument("--re", type=float, default=2000.0)
+    ap.add_argument("--precision", default=os.environ.get("NSFNET_PRECISION", "fp32"),
+                    help="fp32 | bf16x3 | bf16 (or fwd,bwd,dw triple)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -141,7 +143,8 @@ def main():
     L, H, Re = args.layers, args.hidden, args.re
     n_local = args.grid * args.grid
     n_global = n_local * world
-    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, process_group=pg, world_size=world)
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, process_group=pg, world_size=world,
+                       precision=args.precision)
     E.net.set_flat(seeded_flat(L, H))
     x, y = grid_block(args.grid, args.grid, rank, world)
     E.set_collocation(x, y, n_global=n_global)

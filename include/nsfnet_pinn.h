@@ -43,6 +43,12 @@ int pinn_abi_version(void);
  * hidden <= 256 in this release. */
 int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out);
 int pinn_net_destroy(pinn_net_t net);
+/* Arithmetic of the three MFMA kernel families (forward sweep, reverse sweep, weight-gradient
+ * GEMM): 0 = f32-input MFMA (bit-exact fp32 fmaf chains, default), 1 = bf16x3 (fp32 operands
+ * split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~2^-17 relative per
+ * product), 2 = plain bf16 operands (fast mode, does NOT meet the 1e-4 loss-parity bar).
+ * Call before pinn_net_prepare / pinn_plan_create. */
+int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_dw);
 int64_t pinn_net_num_params(pinn_net_t net);
 int64_t pinn_net_prep_floats(pinn_net_t net);
 /* Re-layout the flat parameters into padded MFMA-fragment order; call after every

@@ -14,6 +14,7 @@ SIGNATURES = {
     "pinn_abi_version": (c_int, []),
     "pinn_net_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "pinn_net_destroy": (c_int, [c_void_p]),
+    "pinn_net_set_precision": (c_int, [c_void_p, c_int, c_int, c_int]),
     "pinn_net_num_params": (c_int64, [c_void_p]),
     "pinn_net_prep_floats": (c_int64, [c_void_p]),
     "pinn_net_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,54 @@
+// bf16 split helpers and LDS image geometry of the bf16x3 MFMA path (gfx950).
+//
+// bf16x3: every fp32 operand x is split x = hi + lo (both bf16, RNE) and a product is
+// accumulated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulate (the dropped a_lo*b_lo term is ~2^-18 relative).  Operand layouts were checked
+// on hardware by tests/micro/mfma_bf16_layout.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // lowers to v_cvt_pk_bf16_f32 (RNE)
+  bf16x2_t v;
+  v[0] = (__bf16)a; v[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float bf_lo_f(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi_f(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// four consecutive values -> packed hi (2 dwords) and lo (2 dwords)
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u32x2& hi, u32x2& lo) {
+  unsigned h0 = pack_bf16(x0, x1), h1 = pack_bf16(x2, x3);
+  hi[0] = h0; hi[1] = h1;
+  lo[0] = pack_bf16(x0 - bf_lo_f(h0), x1 - bf_hi_f(h0));
+  lo[1] = pack_bf16(x2 - bf_lo_f(h1), x3 - bf_hi_f(h1));
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ---- activation image in LDS for the fused fwd/bwd kernels -------------------
+// X[hilo(2)][plane j(4)][col(32)][k (RSE)] bf16, RSE = HP rounded up to a power of two
+// (>= 32); 16-byte chunks (8 k) XOR-swizzled so that the ds_read_b128 of one k-chunk by
+// 32 different columns is bank-conflict free.
+template <int HP>
+struct XImg {
+  static constexpr int RSE = HP <= 32 ? 32 : HP <= 64 ? 64 : HP <= 128 ? 128 : 256;
+  static constexpr int NCH = RSE / 8;                    // chunks per row
+  static constexpr int R = RSE >= 128 ? 1 : 128 / RSE;   // rows per 256-byte bank row
+  static constexpr int MASK = (NCH < 16 ? NCH : 16) - 1;
+  static constexpr int PLANE = 32 * RSE;                 // elements per (hilo, j) plane
+  static constexpr int HALF = 4 * PLANE;                 // elements per hilo half
+  static constexpr size_t BYTES = (size_t)2 * HALF * 2;
+  // byte offset (within one plane) of chunk `ch` of column `col`
+  __device__ static __forceinline__ int chunk_off(int col, int ch) {
+    return (col * RSE + ((ch ^ ((col / R) & MASK)) << 3)) * 2;
+  }
+};

@@ -1,0 +1,280 @@
+// bf16x3 (and plain bf16) variant of the fused reverse sweep (see bwd.hip for the algorithm
+// and the reference lines it replaces: loss.backward(), NSFnet/pinn_solver.py:252,
+// ev-NSFnet/pinn_solver.py:469).  G_{l-1} = W_l^T Zb_l runs on v_mfma_f32_32x32x16_bf16 with
+// hi/lo split operands (bf16_util.h); the z-adjoint tile lives in LDS as
+// X[hi|lo][stream][col][k] bf16 (swizzled); Zb spilled to HBM stays fp32 (layout.h).
+#include "kernels.h"
+#include "bf16_util.h"
+
+__device__ __forceinline__ float red32(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+
+template <int HP, int NS, int TERMS>
+__global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
+  using XI = XImg<HP>;
+  constexpr int NT = HP * 2, KS = HP / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* Xb = ldsb;                                       // [2][4][32][RSE] bf16
+  float* oadjL = reinterpret_cast<float*>(ldsb + XI::BYTES);      // [4][128]
+  float* sgacc = oadjL + 4 * 128;                                 // [sg_total]
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ob = w * 32;
+  const float* __restrict__ P = a.prep;
+  const int L = a.L;
+  const int npad = a.ntiles * (NS == 4 ? 32 : 128);
+  const int SG = sg_total(HP, L);
+  for (int i = tid; i < SG; i += NT) sgacc[i] = 0.f;
+  float dbo[3] = {0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // ---------------- output adjoints per column ----------------
+    float px[4], py[4];
+    if (NS == 4) {
+      const int ptc = tile * 32 + col;
+      px[0] = ptc < a.n ? a.x[ptc] : 0.f;
+      py[0] = ptc < a.n ? a.y[ptc] : 0.f;
+      if (tid < 32) {
+        const int pt = tile * 32 + tid;
+        const bool m = pt < a.n;
+        const float* f = a.fld + pt;
+        float u = f[FLD_U * (size_t)npad], v = f[FLD_V * (size_t)npad];
+        float ux = f[FLD_UX * (size_t)npad], uy = f[FLD_UY * (size_t)npad];
+        float vx = f[FLD_VX * (size_t)npad], vy = f[FLD_VY * (size_t)npad];
+        float eq1 = f[FLD_EQ1 * (size_t)npad], eq2 = f[FLD_EQ2 * (size_t)npad];
+        float eq3 = f[FLD_EQ3 * (size_t)npad], eq4 = f[FLD_EQ4 * (size_t)npad];
+        float ww = m ? (a.w ? a.w[pt] : 1.f) : 0.f;
+        float g1 = a.coef_eq[0] * ww * eq1, g2 = a.coef_eq[1] * ww * eq2, g3 = a.coef_eq[2] * ww * eq3;
+        float g4 = a.e ? a.coef_eq[3] * ww * eq4 : 0.f;
+        float r1 = g1 + g4 * (u - 0.5f), r2 = g2 + g4 * (v - 0.5f), r3 = g3;
+        float nu = a.inv_re + ((a.vis_used && m) ? a.vis_used[pt] : 0.f);
+        const float sc = a.scale, sc2 = a.scale * a.scale;
+        float au = r1 * ux + r2 * vx + g4 * eq1;
+        float av = r1 * uy + r2 * vy + g4 * eq2;
+        oadjL[0 * 128 + 0 + tid] = au;
+        oadjL[0 * 128 + 32 + tid] = (r1 * u + r3) * sc;
+        oadjL[0 * 128 + 64 + tid] = (r1 * v) * sc;
+        oadjL[0 * 128 + 96 + tid] = -nu * r1 * sc2;
+        oadjL[1 * 128 + 0 + tid] = av;
+        oadjL[1 * 128 + 32 + tid] = (r2 * u) * sc;
+        oadjL[1 * 128 + 64 + tid] = (r2 * v + r3) * sc;
+        oadjL[1 * 128 + 96 + tid] = -nu * r2 * sc2;
+        oadjL[2 * 128 + 0 + tid] = 0.f;
+        oadjL[2 * 128 + 32 + tid] = r1 * sc;
+        oadjL[2 * 128 + 64 + tid] = r2 * sc;
+        oadjL[2 * 128 + 96 + tid] = 0.f;
+        if (a.ebar && m) a.ebar[pt] = -g4;
+        dbo[0] += au; dbo[1] += av;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int pt = tile * 128 + 32 * j + col;
+        px[j] = pt < a.n ? a.x[pt] : 0.f;
+        py[j] = pt < a.n ? a.y[pt] : 0.f;
+      }
+      for (int idx = tid; idx < 3 * 128; idx += NT) {
+        int c = idx >> 7, cc = idx & 127;
+        int pt = tile * 128 + cc;
+        float v = (c < a.n_out && pt < a.n) ? a.oadj[(size_t)c * npad + pt] : 0.f;
+        oadjL[idx] = v;
+        if (c == 0) dbo[0] += v; else if (c == 1) dbo[1] += v; else dbo[2] += v;
+      }
+    }
+    __syncthreads();
+    // ---------------- adjoint of the last hidden layer's activations (3 -> HP, rank-3) ----------------
+    f32x16 acc[4];
+    float oa[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oa[c][j] = oadjL[c * 128 + 32 * j + col];
+    {
+      const float* wo = P + prep_wout(HP, L);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = ob + mfma_row(r, h);
+        float w0 = wo[o], w1 = wo[HP + o], w2 = wo[2 * HP + o];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j][r] = w0 * oa[0][j] + w1 * oa[1][j] + w2 * oa[2][j];
+      }
+    }
+    for (int l = L - 1; l >= 0; --l) {
+      const float* Sl = a.S + ((size_t)tile * L + l) * act_block(HP);
+      float* Zl = a.Zb + ((size_t)tile * L + l) * act_block(HP);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
+        f32x4 s0 = Sg[0 * (HP / 4) * 32], s1 = Sg[1 * (HP / 4) * 32];
+        f32x4 s2 = Sg[2 * (HP / 4) * 32], s3 = Sg[3 * (HP / 4) * 32];
+        f32x4 z0, z1, z2, z3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int o = ob + 8 * g + 4 * h + e;
+          float zb, dbv, dwx, dwy;
+          float wo0 = 0.f, wo1 = 0.f, wo2 = 0.f;
+          if (NS == 4) {
+            float t = s0[e], zx = s1[e], zy = s2[e], zd = s3[e];
+            float d1 = 1.f - t * t;
+            float d2 = -2.f * t * d1;
+            float d3 = -2.f * d1 * (1.f - 3.f * t * t);
+            float ga = acc[0][r], gx = acc[1][r], gy = acc[2][r], gd = acc[3][r];
+            if (l == L - 1) {   // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
+              float ax = d1 * zx, ay = d1 * zy, ad = d2 * (zx * zx + zy * zy) + d1 * zd;
+              wo0 = oa[0][0] * t + oa[0][1] * ax + oa[0][2] * ay + oa[0][3] * ad;
+              wo1 = oa[1][0] * t + oa[1][1] * ax + oa[1][2] * ay + oa[1][3] * ad;
+              wo2 = oa[2][0] * t + oa[2][1] * ax + oa[2][2] * ay + oa[2][3] * ad;
+            }
+            float zbx = d1 * gx + 2.f * d2 * zx * gd;
+            float zby = d1 * gy + 2.f * d2 * zy * gd;
+            float zbd = d1 * gd;
+            zb = d1 * ga + d2 * (zx * gx + zy * gy) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd;
+            z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
+            dbv = zb;
+            dwx = zb * px[0] + zbx;
+            dwy = zb * py[0] + zby;
+          } else {
+            float zq[4];
+            dbv = 0.f; dwx = 0.f; dwy = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float t = (j == 0 ? s0[e] : j == 1 ? s1[e] : j == 2 ? s2[e] : s3[e]);
+              if (l == L - 1) { wo0 += oa[0][j] * t; wo1 += oa[1][j] * t; wo2 += oa[2][j] * t; }
+              zq[j] = (1.f - t * t) * acc[j][r];
+              dbv += zq[j]; dwx += zq[j] * px[j]; dwy += zq[j] * py[j];
+            }
+            z0[e] = zq[0]; z1[e] = zq[1]; z2[e] = zq[2]; z3[e] = zq[3];
+          }
+          // skinny gradients: sum over the 32 columns held by this half-wave
+          dbv = red32(dbv);
+          if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
+          if (l == L - 1) {
+            wo0 = red32(wo0); wo1 = red32(wo1); wo2 = red32(wo2);
+            if (col == 0) {
+              sgacc[sg_wout(HP, L) + o] += wo0;
+              sgacc[sg_wout(HP, L) + HP + o] += wo1;
+              sgacc[sg_wout(HP, L) + 2 * HP + o] += wo2;
+            }
+          }
+          if (l == 0) {
+            dwx = red32(dwx); dwy = red32(dwy);
+            if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
+          }
+        }
+        if (l > 0) {
+          const int off = XI::chunk_off(col, (ob >> 3) + g) + 8 * h;
+          u32x2 hi, lo;
+          split4(z0[0], z0[1], z0[2], z0[3], hi, lo);
+          *reinterpret_cast<u32x2*>(Xb + 0 * XI::PLANE * 2 + off) = hi;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 0 * XI::PLANE * 2 + off) = lo;
+          split4(z1[0], z1[1], z1[2], z1[3], hi, lo);
+          *reinterpret_cast<u32x2*>(Xb + 1 * XI::PLANE * 2 + off) = hi;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 1 * XI::PLANE * 2 + off) = lo;
+          split4(z2[0], z2[1], z2[2], z2[3], hi, lo);
+          *reinterpret_cast<u32x2*>(Xb + 2 * XI::PLANE * 2 + off) = hi;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 2 * XI::PLANE * 2 + off) = lo;
+          split4(z3[0], z3[1], z3[2], z3[3], hi, lo);
+          *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = hi;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = lo;
+          f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
+          Zg[0 * (HP / 4) * 32] = z0; Zg[1 * (HP / 4) * 32] = z1;
+          Zg[2 * (HP / 4) * 32] = z2; Zg[3 * (HP / 4) * 32] = z3;
+        }
+      }
+      if (l == 0) break;
+      __syncthreads();
+      // ------------- G_{l-1}[i][col] = sum_o W_l[o][i] Zb_l[o][col]  (bf16 MFMA) -------------
+      {
+        const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l)) + (size_t)w * KS * 64 + lane;
+        u32x4 ah[KS], al[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          ah[s] = wf[s * 64];
+          if (TERMS == 3) al[s] = wf[(size_t)(HP * HP / 8) + s * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const int off = XI::chunk_off(col, 2 * s + h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u32x4 bh = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
+            if (TERMS == 3) {
+              u32x4 bo = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+              acc[j] = mfma_bf16(ah[s], bo, acc[j]);
+              acc[j] = mfma_bf16(al[s], bh, acc[j]);
+            }
+            acc[j] = mfma_bf16(ah[s], bh, acc[j]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  // ---------------- flush ----------------
+  // output-bias gradient: per-thread partials -> fixed-order sum
+  float* red = reinterpret_cast<float*>(ldsb);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 3; ++c) red[c * NT + tid] = dbo[c];
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.f;
+    for (int t = 0; t < NT; ++t) s += red[tid * NT + t];
+    sgacc[sg_bout(HP, L) + tid] = s;
+  }
+  __syncthreads();
+  float* out = a.sg + (size_t)blockIdx.x * SG;
+  for (int i = tid; i < SG; i += NT) out[i] = sgacc[i];
+}
+
+template <int HP>
+static size_t lds_bytes_t(int L) { return XImg<HP>::BYTES + ((size_t)4 * 128 + sg_total(HP, L)) * sizeof(float); }
+
+size_t bwd_bf16_lds_bytes(int HP, int L) {
+  switch (HP) {
+    case 32: return lds_bytes_t<32>(L); case 64: return lds_bytes_t<64>(L); case 96: return lds_bytes_t<96>(L);
+    case 128: return lds_bytes_t<128>(L); case 160: return lds_bytes_t<160>(L); case 192: return lds_bytes_t<192>(L);
+    case 224: return lds_bytes_t<224>(L); default: return lds_bytes_t<256>(L);
+  }
+}
+
+template <int HP, int NS, int TERMS>
+static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
+  size_t lds = lds_bytes_t<HP>(a.L);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_bf16_kernel<HP, NS, TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((bwd_bf16_kernel<HP, NS, TERMS>), dim3(grid), dim3(HP * 2), lds, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+#define BWD_CASE(hp)                                                                         \
+  case hp:                                                                                   \
+    if (terms == 3) return NS == 4 ? launch_one<hp, 4, 3>(a, grid, s) : launch_one<hp, 1, 3>(a, grid, s); \
+    return NS == 4 ? launch_one<hp, 4, 1>(a, grid, s) : launch_one<hp, 1, 1>(a, grid, s);
+
+int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s) {
+  switch (HP) {
+    BWD_CASE(32) BWD_CASE(64) BWD_CASE(96) BWD_CASE(128)
+    BWD_CASE(160) BWD_CASE(192) BWD_CASE(224) BWD_CASE(256)
+    default: return -1000;
+  }
+}

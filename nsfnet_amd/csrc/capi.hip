@@ -20,9 +20,12 @@ static int hipfail(int rc, const char* what) {
   return fail(rc, "%s: HIP error %ld", what, (long)-rc);
 }
 
+// precision of a kernel family: 0 = fp32-input MFMA (exact fp32), 1 = bf16x3 split, 2 = plain bf16
 struct pinn_net_s {
   int n_out, L, H, HP;
+  int prec_fwd, prec_bwd, prec_dw;
 };
+static int terms_of(int prec) { return prec == 1 ? 3 : 1; }
 
 struct pinn_plan_s {
   pinn_net_s net;
@@ -60,7 +63,15 @@ int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out)
   pinn_net_s* n = new (std::nothrow) pinn_net_s;
   if (!n) return fail(-12, "pinn_net_create: out of host memory%s");
   n->n_out = n_out; n->L = n_hidden_layers; n->H = hidden; n->HP = (hidden + 31) / 32 * 32;
+  n->prec_fwd = n->prec_bwd = n->prec_dw = 0;
   *out = n;
+  return 0;
+}
+int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_dw) {
+  if (!net) return fail(-22, "pinn_net_set_precision: null net%s");
+  if (prec_fwd < 0 || prec_fwd > 2 || prec_bwd < 0 || prec_bwd > 2 || prec_dw < 0 || prec_dw > 2)
+    return fail(-22, "pinn_net_set_precision: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16)%s");
+  net->prec_fwd = prec_fwd; net->prec_bwd = prec_bwd; net->prec_dw = prec_dw;
   return 0;
 }
 int pinn_net_destroy(pinn_net_t net) { delete net; return 0; }
@@ -69,7 +80,8 @@ int64_t pinn_net_prep_floats(pinn_net_t net) { return net ? (int64_t)prep_total(
 
 int pinn_net_prepare(pinn_net_t net, const float* params, float* prep, void* stream) {
   if (!net || !params || !prep) return fail(-22, "pinn_net_prepare: null argument%s");
-  int rc = launch_prep(params, prep, net->H, net->HP, net->L, net->n_out, (hipStream_t)stream);
+  int rc = launch_prep(params, prep, net->H, net->HP, net->L, net->n_out, net->prec_fwd, net->prec_bwd,
+                       (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_net_prepare") : 0;
 }
 
@@ -92,12 +104,15 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     if (b > bw) b = bw;
     return b < 1 ? 1 : b;
   };
-  p->grid_f = cus * bpc(fwd_lds_bytes(HP));
+  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP) : fwd_lds_bytes(HP);
+  const size_t lds_b = net->prec_bwd ? bwd_bf16_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
+  const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : dw_lds_bytes(HP);
+  p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
-  p->grid_b = cus * bpc(bwd_lds_bytes(HP, L));
+  p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
   if (L > 1) {
-    int g = cus * bpc(dw_lds_bytes(HP)) / (L - 1);
+    int g = cus * bpc(lds_d) / (L - 1);
     if (g < 1) g = 1;
     if (g > p->ntiles) g = p->ntiles;
     p->groups = g;
@@ -140,7 +155,8 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.fld = fields; a.e = e; a.w = w; a.vtm = vis_t_minus; a.vis_used = vis_t_out;
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
-  int rc = launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
+  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                              : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -154,7 +170,8 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
-  return launch_dw(plan->net.HP, plan->streams, d, s);
+  return plan->net.prec_dw ? launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s)
+                           : launch_dw(plan->net.HP, plan->streams, d, s);
 }
 
 int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
@@ -173,7 +190,8 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {
-    rc = launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+    rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                            : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
   }
   if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
@@ -206,7 +224,8 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = save ? WS(plan, off_oadj) : nullptr;
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
-  int rc = launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
+  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                              : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -226,7 +245,8 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
-  int rc = launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
+  int rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                              : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");
   rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;
@@ -244,7 +264,7 @@ int pinn_grad_reduce(pinn_net_t net, int nsrc, const pinn_plan_t* plans, void* c
     pinn_plan_t p = plans[k];
     void* ws = wss[k];
     if (!p || !ws) return fail(-22, "pinn_grad_reduce: null plan/workspace%s");
-    if (p->net.H != net->H || p->net.L != net->L || p->net.n_out != net->n_out)
+    if (p->net.H != net->H || p->net.L != net->L || p->net.n_out != net->n_out)  // (precision may differ)
       return fail(-22, "pinn_grad_reduce: plan belongs to a different net%s");
     r.src[k].slabs = WS(p, off_slabs); r.src[k].groups = p->groups;
     r.src[k].sg = WS(p, off_sg); r.src[k].nwg = p->grid_b;

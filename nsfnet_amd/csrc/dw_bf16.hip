@@ -1,0 +1,198 @@
+// bf16x3 (and plain bf16) variant of the weight-gradient GEMM (see dw.hip for the algorithm
+// and the reference lines it replaces).  dW_l[o][i] = sum_col Zb_l[o][col] A_{l-1}[i][col]:
+// the contraction index is the column (point, stream), which is the ROW index of the natural
+// staging image [col][feature]; ds_read_b64_tr_b16 delivers the K-along-rows fragments the
+// 32x32x16 bf16 MFMA wants (lane map verified by tests/micro/mfma_bf16_layout.hip), so the
+// images are written with plain 8-byte stores and no second (transposed) copy exists.
+#include "kernels.h"
+#include "bf16_util.h"
+
+template <int T> struct DwCfgB;
+template <> struct DwCfgB<1> { static constexpr int TM = 1, TN = 1; };
+template <> struct DwCfgB<2> { static constexpr int TM = 1, TN = 2; };
+template <> struct DwCfgB<3> { static constexpr int TM = 1, TN = 3; };
+template <> struct DwCfgB<4> { static constexpr int TM = 2, TN = 2; };
+template <> struct DwCfgB<5> { static constexpr int TM = 1, TN = 5; };
+template <> struct DwCfgB<6> { static constexpr int TM = 2, TN = 3; };
+template <> struct DwCfgB<7> { static constexpr int TM = 1, TN = 7; };
+template <> struct DwCfgB<8> { static constexpr int TM = 4, TN = 2; };
+
+template <int HP>
+struct DwImg {
+  static constexpr int PADB = ((64 - 2 * HP) % 256 + 256) % 256;   // row stride == 64 (mod 256) bytes
+  static constexpr int RSB = 2 * HP + PADB;                         // row stride in bytes
+  static constexpr int CH = 32;                                     // columns (rows of the image) per chunk
+  static constexpr int ARR = CH * RSB;                              // bytes per array per buffer
+  // arrays: 0 = Z hi, 1 = Z lo, 2 = A hi, 3 = A lo
+  static constexpr size_t BYTES = (size_t)2 * 4 * ARR;
+};
+
+// ds_read_b64_tr_b16 through the compiler builtin (hipcc tracks its lgkmcnt itself)
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  return __builtin_bit_cast(u32x2, v);
+}
+
+template <int HP, int NS, int TERMS>
+__global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
+  using DI = DwImg<HP>;
+  constexpr int T = HP / 32;
+  constexpr int TM = DwCfgB<T>::TM, TN = DwCfgB<T>::TN;
+  constexpr int WN = T / TN;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  const int tid = threadIdx.x, lane = tid & 63, i32 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w / WN, wc = w % WN;
+  const int l = blockIdx.y + 1;
+  const int g = blockIdx.x;
+  const int t0 = (int)((long)g * a.ntiles / a.groups), t1 = (int)((long)(g + 1) * a.ntiles / a.groups);
+  const int nch = (t1 - t0) * 4;
+  const int p = tid & 7, og = tid >> 3;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  f32x4 zr[4], sr[4];
+  auto gload = [&](int ch) {
+    const int tile = t0 + (ch >> 2), c = ch & 3;
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
+    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      zr[s] = Zg[(size_t)s * (HP / 4) * 32];
+      sr[s] = Sg[(size_t)s * (HP / 4) * 32];
+    }
+  };
+  auto lstore = [&](int buf) {
+    f32x4 av[4];
+    if (NS == 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = sr[0][e], zx = sr[1][e], zy = sr[2][e], zd = sr[3][e];
+        float d1 = 1.f - t * t, d2 = -2.f * t * d1;
+        av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
+      }
+    } else {
+      av[0] = sr[0]; av[1] = sr[1]; av[2] = sr[2]; av[3] = sr[3];
+    }
+    unsigned char* base = ldsb + (size_t)buf * 4 * DI::ARR + p * DI::RSB + og * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      u32x2 hi, lo;
+      unsigned char* row = base + s * 8 * DI::RSB;
+      split4(zr[s][0], zr[s][1], zr[s][2], zr[s][3], hi, lo);
+      *reinterpret_cast<u32x2*>(row + 0 * DI::ARR) = hi;
+      if (TERMS == 3) *reinterpret_cast<u32x2*>(row + 1 * DI::ARR) = lo;
+      split4(av[s][0], av[s][1], av[s][2], av[s][3], hi, lo);
+      *reinterpret_cast<u32x2*>(row + 2 * DI::ARR) = hi;
+      if (TERMS == 3) *reinterpret_cast<u32x2*>(row + 3 * DI::ARR) = lo;
+    }
+  };
+
+  if (nch > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  // transposed-read lane geometry: 16-lane group gq = lane>>4 -> feature half fb, k half (== h)
+  const int li = lane & 15, fb = (lane >> 4) & 1, q = li >> 2, pp = li & 3;
+  const int lane_off = (8 * h + q) * DI::RSB + (16 * fb + 4 * pp) * 2;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) gload(ch + 1);
+    const unsigned char* B0 = ldsb + (size_t)buf * 4 * DI::ARR + lane_off;
+#pragma unroll
+    for (int ks = 0; ks < DI::CH / 16; ++ks) {
+      u32x4 zh[TM], zl[TM], ah[TN], al[TN];
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const unsigned char* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
+        u32x2 x0 = tr_read(pz), x1 = tr_read(pz + 4 * DI::RSB);
+        zh[m][0] = x0[0]; zh[m][1] = x0[1]; zh[m][2] = x1[0]; zh[m][3] = x1[1];
+        if (TERMS == 3) {
+          u32x2 y0 = tr_read(pz + DI::ARR), y1 = tr_read(pz + DI::ARR + 4 * DI::RSB);
+          zl[m][0] = y0[0]; zl[m][1] = y0[1]; zl[m][2] = y1[0]; zl[m][3] = y1[1];
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const unsigned char* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
+        u32x2 x0 = tr_read(pa), x1 = tr_read(pa + 4 * DI::RSB);
+        ah[n][0] = x0[0]; ah[n][1] = x0[1]; ah[n][2] = x1[0]; ah[n][3] = x1[1];
+        if (TERMS == 3) {
+          u32x2 y0 = tr_read(pa + DI::ARR), y1 = tr_read(pa + DI::ARR + 4 * DI::RSB);
+          al[n][0] = y0[0]; al[n][1] = y0[1]; al[n][2] = y1[0]; al[n][3] = y1[1];
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          if (TERMS == 3) {
+            acc[m][n] = mfma_bf16(zh[m], al[n], acc[m][n]);
+            acc[m][n] = mfma_bf16(zl[m], ah[n], acc[m][n]);
+          }
+          acc[m][n] = mfma_bf16(zh[m], ah[n], acc[m][n]);
+        }
+    }
+    if (ch + 1 < nch) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  float* slab = a.slabs + ((size_t)(l - 1) * a.groups + g) * HP * HP;
+#pragma unroll
+  for (int m = 0; m < TM; ++m)
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int o = 32 * (wr * TM + m) + mfma_row(r, h);
+        int i = 32 * (wc * TN + n) + i32;
+        slab[(size_t)o * HP + i] = acc[m][n][r];
+      }
+}
+
+template <int HP>
+static size_t lds_bytes_t() { return DwImg<HP>::BYTES; }
+
+size_t dw_bf16_lds_bytes(int HP) {
+  switch (HP) {
+    case 32: return lds_bytes_t<32>(); case 64: return lds_bytes_t<64>(); case 96: return lds_bytes_t<96>();
+    case 128: return lds_bytes_t<128>(); case 160: return lds_bytes_t<160>(); case 192: return lds_bytes_t<192>();
+    case 224: return lds_bytes_t<224>(); default: return lds_bytes_t<256>();
+  }
+}
+
+template <int HP, int NS, int TERMS>
+static int launch_one(const DwArgs& a, hipStream_t s) {
+  size_t lds = lds_bytes_t<HP>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+#define DW_CASE(hp)                                                                   \
+  case hp:                                                                            \
+    if (terms == 3) return NS == 4 ? launch_one<hp, 4, 3>(a, s) : launch_one<hp, 1, 3>(a, s); \
+    return NS == 4 ? launch_one<hp, 4, 1>(a, s) : launch_one<hp, 1, 1>(a, s);
+
+int launch_dw_bf16(int HP, int NS, int terms, const DwArgs& a, hipStream_t s) {
+  if (a.L <= 1 || a.groups <= 0) return 0;
+  switch (HP) {
+    DW_CASE(32) DW_CASE(64) DW_CASE(96) DW_CASE(128)
+    DW_CASE(160) DW_CASE(192) DW_CASE(224) DW_CASE(256)
+    default: return -1000;
+  }
+}

@@ -71,7 +71,15 @@ size_t bwd_lds_bytes(int HP, int L);
 size_t dw_lds_bytes(int HP);
 int dw_threads(int HP);
 
-int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, hipStream_t s);
+int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, int prec_fwd, int prec_bwd,
+                hipStream_t s);
+// bf16 MFMA variants (terms = 3: bf16x3 split, terms = 1: plain bf16)
+int launch_fwd_bf16(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
+int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);
+int launch_dw_bf16(int HP, int NS, int terms, const DwArgs& a, hipStream_t s);
+size_t fwd_bf16_lds_bytes(int HP);
+size_t bwd_bf16_lds_bytes(int HP, int L);
+size_t dw_bf16_lds_bytes(int HP);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float step_size, float b1, float b2,

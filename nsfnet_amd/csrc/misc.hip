@@ -7,8 +7,27 @@
 // ordered copies (layout.h).  Wf: lane (i = lane&31, h = lane>>5) of wave w holds
 // W[32w+i][2ks+h] for ks = 0..HP/2-1, four ks per 16-byte load.  WTf: same with W^T.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f2bf_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// bf16 fragment element `pos` (0 .. HP*HP-1) of the hi (lo_part = 0) or lo (lo_part = 1) array:
+// wave w, k-step s, lane (r = lane&31, h = lane>>5), element j holds W[32w+r][16s+8h+j] (or W^T).
+__device__ __forceinline__ unsigned short bf16_frag_elem(const float* W, int H, int HP, bool tr, int pos, int lo_part) {
+  int j = pos & 7, lane = (pos >> 3) & 63, ws = pos >> 9;
+  int KS = HP / 16, s = ws % KS, w = ws / KS;
+  int k = 16 * s + 8 * (lane >> 5) + j, o = 32 * w + (lane & 31);
+  float v = 0.f;
+  if (o < H && k < H) v = tr ? W[(size_t)k * H + o] : W[(size_t)o * H + k];
+  unsigned short hi = f2bf_rne(v);
+  if (!lo_part) return hi;
+  return f2bf_rne(v - __uint_as_float(((unsigned)hi) << 16));
+}
+
 __global__ void prep_kernel(const float* __restrict__ params, float* __restrict__ prep,
-                            int H, int HP, int L, int n_out) {
+                            int H, int HP, int L, int n_out, int prec_fwd, int prec_bwd) {
   const size_t total = prep_total(HP, L);
   for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -25,6 +44,13 @@ __global__ void prep_kernel(const float* __restrict__ params, float* __restrict_
       if (q < (size_t)2 * HP * HP) {
         bool tr = q >= (size_t)HP * HP;
         size_t f = tr ? q - (size_t)HP * HP : q;
+        if ((tr ? prec_bwd : prec_fwd) != 0) {      // bf16 fragments: [hi HP*HP bf16][lo HP*HP bf16]
+          int e0 = (int)(2 * f), half = HP * HP;
+          unsigned short b0 = bf16_frag_elem(W, H, HP, tr, e0 % half, e0 / half);
+          unsigned short b1 = bf16_frag_elem(W, H, HP, tr, (e0 + 1) % half, (e0 + 1) / half);
+          prep[idx] = __uint_as_float((unsigned)b0 | ((unsigned)b1 << 16));
+          continue;
+        }
         int e = (int)(f & 3), lane = (int)((f >> 2) & 63);
         int wq = (int)(f >> 8);
         int qq = wq % (HP / 8), w = wq / (HP / 8);
@@ -46,11 +72,12 @@ __global__ void prep_kernel(const float* __restrict__ params, float* __restrict_
   }
 }
 
-int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, hipStream_t s) {
+int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, int prec_fwd, int prec_bwd,
+                hipStream_t s) {
   size_t total = prep_total(HP, L);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, params, prep, H, HP, L, n_out);
+  hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, params, prep, H, HP, L, n_out, prec_fwd, prec_bwd);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -40,15 +40,34 @@ def layer_shapes(n_out, n_hidden, hidden):
     return [(widths[i + 1], widths[i]) for i in range(len(widths) - 1)]
 
 
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def resolve_precision(precision=None):
+    """'fp32' | 'bf16x3' | 'bf16' or a (fwd, bwd, dw) triple of those; default from
+    $NSFNET_PRECISION, else fp32 (the bit-exact fp32 MFMA path)."""
+    import os
+    if precision is None:
+        precision = os.environ.get("NSFNET_PRECISION", "fp32")
+    if isinstance(precision, str):
+        precision = tuple(precision.split(",")) if "," in precision else (precision,) * 3
+    if len(precision) != 3 or any(p not in PRECISIONS for p in precision):
+        raise ValueError("precision must be one of %s (or a fwd,bwd,dw triple)" % sorted(PRECISIONS))
+    return tuple(precision)
+
+
 class DeviceNet:
     """One FCNet on the device: flat fp32 parameters in reference state_dict order
     (NSFnet/net.py:36-46) plus their MFMA-fragment-ordered copy."""
 
-    def __init__(self, n_out, n_hidden, hidden, device):
+    def __init__(self, n_out, n_hidden, hidden, device, precision=None):
         self.lib = _lib.load()
         self.n_out, self.n_hidden, self.hidden, self.device = n_out, n_hidden, hidden, device
+        self.precision = resolve_precision(precision)
         h = ctypes.c_void_p()
         _lib.check(self.lib.pinn_net_create(n_out, n_hidden, hidden, ctypes.byref(h)), "pinn_net_create")
+        _lib.check(self.lib.pinn_net_set_precision(h, *[PRECISIONS[p] for p in self.precision]),
+                   "pinn_net_set_precision")
         self.handle = h
         self.num_params = int(self.lib.pinn_net_num_params(h))
         self.params = torch.zeros(self.num_params, dtype=torch.float32, device=device)
@@ -232,7 +251,7 @@ class PinnEngine:
 
     def __init__(self, device, n_hidden, hidden, Re, alpha_b=1.0, alpha_e=1.0, flavour="nsfnet",
                  n_hidden_e=None, hidden_e=None, alpha_evm=0.0, alpha_s=0.0, coord_scale=1.0,
-                 vis_t0_factor=20.0, process_group=None, world_size=1, net=None, net_e=None):
+                 vis_t0_factor=20.0, process_group=None, world_size=1, net=None, net_e=None, precision=None):
         self.device = torch.device(device)
         self.flavour = flavour
         self.Re = float(Re)
@@ -240,9 +259,9 @@ class PinnEngine:
         self.alpha_evm = float(alpha_evm)
         self.scale = float(coord_scale)
         self.vis_t0 = vis_t0_factor / self.Re
-        self.net = net if net is not None else DeviceNet(3, n_hidden, hidden, self.device)
+        self.net = net if net is not None else DeviceNet(3, n_hidden, hidden, self.device, precision)
         if flavour == "ev":
-            self.net_e = net_e if net_e is not None else DeviceNet(1, n_hidden_e, hidden_e, self.device)
+            self.net_e = net_e if net_e is not None else DeviceNet(1, n_hidden_e, hidden_e, self.device, precision)
         else:
             self.net_e = None
         self.e_trainable = False

@@ -14,7 +14,7 @@ from oracle import fwdmode_ref as fr
 
 
 class FakeDeviceNet(eng.DeviceNet):
-    def __init__(self, n_out, n_hidden, hidden, device):
+    def __init__(self, n_out, n_hidden, hidden, device, precision=None):
         self.lib = None
         self.handle = None
         self.n_out, self.n_hidden, self.hidden, self.device = n_out, n_hidden, hidden, torch.device("cpu")
