@@ -19,6 +19,7 @@ template <int HP, int NS, int TERMS>
 __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
   using XI = XImg<HP>;
   constexpr int NT = HP * 2, KS = HP / 16;
+  constexpr int PRE = KS < 4 ? KS : 4, RING = (PRE + 2 < KS) ? PRE + 2 : KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* Xb = ldsb;                                       // [2][4][32][RSE] bf16
   float* oadjL = reinterpret_cast<float*>(ldsb + XI::BYTES);      // [4][128]
@@ -107,6 +108,17 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
       }
     }
     for (int l = L - 1; l >= 0; --l) {
+      // W_l^T fragments are requested before this layer's Zb stores (in-order vmcnt, see fwd_bf16.hip)
+      u32x4 wh[RING], wl[RING];
+      const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l > 0 ? l : 1)) + (size_t)w * KS * 64 + lane;
+      if (l > 0) {
+#pragma unroll
+        for (int s = 0; s < PRE; ++s) {
+          wh[s] = wf[s * 64];
+          if (TERMS == 3) wl[s] = wf[(size_t)(HP * HP / 8) + s * 64];
+        }
+      }
+      asm volatile("" ::: "memory");
       const float* Sl = a.S + ((size_t)tile * L + l) * act_block(HP);
       float* Zl = a.Zb + ((size_t)tile * L + l) * act_block(HP);
 #pragma unroll
@@ -193,29 +205,45 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
       __syncthreads();
       // ------------- G_{l-1}[i][col] = sum_o W_l[o][i] Zb_l[o][col]  (bf16 MFMA) -------------
       {
-        const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l)) + (size_t)w * KS * 64 + lane;
-        u32x4 ah[KS], al[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          ah[s] = wf[s * 64];
-          if (TERMS == 3) al[s] = wf[(size_t)(HP * HP / 8) + s * 64];
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int off = XI::chunk_off(col, 2 * s + h);
+        u32x4 bh[4], bo[4];
+        {
+          const int off0 = XI::chunk_off(col, h);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            u32x4 bh = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
-            if (TERMS == 3) {
-              u32x4 bo = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
-              acc[j] = mfma_bf16(ah[s], bo, acc[j]);
-              acc[j] = mfma_bf16(al[s], bh, acc[j]);
+            bh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off0);
+            if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off0);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (s + PRE < KS) {
+            wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
+            if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
+          }
+          u32x4 nh[4], no[4];
+          if (s + 1 < KS) {
+            const int off = XI::chunk_off(col, 2 * (s + 1) + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              nh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
+              if (TERMS == 3) no[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
             }
-            acc[j] = mfma_bf16(ah[s], bh, acc[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (TERMS == 3) {
+              acc[j] = mfma_bf16(wh[s % RING], bo[j], acc[j]);
+              acc[j] = mfma_bf16(wl[s % RING], bh[j], acc[j]);
+            }
+            acc[j] = mfma_bf16(wh[s % RING], bh[j], acc[j]);
+          }
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bh[j] = nh[j]; if (TERMS == 3) bo[j] = no[j]; }
           }
         }
       }

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 #include "../../include/nsfnet_pinn.h"
@@ -49,6 +50,11 @@ static int num_cus() {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 extern "C" {
 
@@ -104,7 +110,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     if (b > bw) b = bw;
     return b < 1 ? 1 : b;
   };
-  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP) : fwd_lds_bytes(HP);
+  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP, L) : fwd_lds_bytes(HP);
   const size_t lds_b = net->prec_bwd ? bwd_bf16_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
   const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : dw_lds_bytes(HP);
   p->grid_f = cus * bpc(lds_f);
@@ -155,6 +161,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.fld = fields; a.e = e; a.w = w; a.vtm = vis_t_minus; a.vis_used = vis_t_out;
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
+  a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 1) : 0;
   int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
                               : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");

@@ -17,10 +17,12 @@ template <int HP, int NS, int TERMS>
 __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
   using XI = XImg<HP>;
   constexpr int NW = HP / 32, NT = HP * 2, KS = HP / 16;
+  constexpr int PRE = KS < 4 ? KS : 4, RING = (PRE + 2 < KS) ? PRE + 2 : KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* Xb = ldsb;                                   // [2][4][32][RSE] bf16
   float* part = reinterpret_cast<float*>(ldsb + XI::BYTES);   // [NW][4][128]
   float* outv = part + NW * 4 * 128;                          // [4][128]
+  float* biasL = outv + 4 * 128;                              // [L][HP] hidden-layer biases (l >= 1)
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ob = w * 32;
@@ -28,6 +30,14 @@ __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
   const int L = a.L;
   const int npad = a.ntiles * (NS == 4 ? 32 : 128);
   float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < (a.L - 1) * HP; i += NT) biasL[HP + i] = a.prep[prep_b(HP, 1 + i / HP) + (i % HP)];
+  // De-phase the workgroups: every workgroup runs the same store-burst / MFMA cadence, and in
+  // lockstep the whole chip hits HBM in the same windows.  A one-off start offset spreads them.
+  if (a.stagger > 0) {
+    const int slots = (blockIdx.x * 5) & 7;
+    for (int i = 0; i < slots * a.stagger; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+  __syncthreads();
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     f32x16 acc[4];
@@ -59,6 +69,21 @@ __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
       }
     }
     for (int l = 0; l < L; ++l) {
+      // Next layer's weight fragments and bias are requested BEFORE this layer's activation
+      // stores: vmcnt retires in order, so a weight load issued behind the 16 S stores would
+      // make the MFMA loop wait for the whole HBM store burst.
+      // (only the first PRE k-steps; the rest stream through a small register ring inside the MFMA
+      // loop so that the B fragments can be double-buffered: see gemm_ring below)
+      u32x4 wh[RING], wl[RING];
+      const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wf(HP, l + 1 < L ? l + 1 : 1)) + (size_t)w * KS * 64 + lane;
+      if (l < L - 1) {
+#pragma unroll
+        for (int s = 0; s < PRE; ++s) {
+          wh[s] = wf[s * 64];
+          if (TERMS == 3) wl[s] = wf[(size_t)(HP * HP / 8) + s * 64];
+        }
+      }
+      asm volatile("" ::: "memory");
       float* Sl = a.S ? a.S + ((size_t)tile * L + l) * act_block(HP) : nullptr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -68,15 +93,15 @@ __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           if (NS == 4) {
-            float t = tanhf(acc[0][r]);
+            float t = fast_tanh(acc[0][r]);
             float zx = acc[1][r], zy = acc[2][r], zd = acc[3][r];
             float d1 = 1.f - t * t;
             float d2 = -2.f * t * d1;
             a0[e] = t; a1[e] = d1 * zx; a2[e] = d1 * zy; a3[e] = d2 * (zx * zx + zy * zy) + d1 * zd;
             s0[e] = t; s1[e] = zx; s2[e] = zy; s3[e] = zd;
           } else {
-            a0[e] = s0[e] = tanhf(acc[0][r]); a1[e] = s1[e] = tanhf(acc[1][r]);
-            a2[e] = s2[e] = tanhf(acc[2][r]); a3[e] = s3[e] = tanhf(acc[3][r]);
+            a0[e] = s0[e] = fast_tanh(acc[0][r]); a1[e] = s1[e] = fast_tanh(acc[1][r]);
+            a2[e] = s2[e] = fast_tanh(acc[2][r]); a3[e] = s3[e] = fast_tanh(acc[3][r]);
           }
         }
         // restage as bf16 hi/lo: 4 consecutive features = 8 bytes at [col][chunk (ob/8+g)] + 8h
@@ -103,38 +128,54 @@ __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
           Sg[2 * (HP / 4) * 32] = s2;
           Sg[3 * (HP / 4) * 32] = s3;
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the four register quads sequential (VGPR budget)
       }
       __syncthreads();
       if (l == L - 1) break;
       // ------------- hidden GEMM l+1 on bf16 MFMA -------------
       {
-        const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wf(HP, l + 1)) + (size_t)w * KS * 64 + lane;
-        u32x4 ah[KS], al[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          ah[s] = wf[s * 64];
-          if (TERMS == 3) al[s] = wf[(size_t)(HP * HP / 8) + s * 64];
-        }
-        const float* bl = P + prep_b(HP, l + 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float b = bl[ob + mfma_row(r, h)];
+          float b = biasL[(l + 1) * HP + ob + mfma_row(r, h)];
           acc[0][r] = b;
           if (NS == 4) { acc[1][r] = 0.f; acc[2][r] = 0.f; acc[3][r] = 0.f; }
           else { acc[1][r] = b; acc[2][r] = b; acc[3][r] = b; }
         }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int off = XI::chunk_off(col, 2 * s + h);
+        u32x4 bh[4], bo[4];
+        {
+          const int off0 = XI::chunk_off(col, h);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            u32x4 bh = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
-            if (TERMS == 3) {
-              u32x4 bo = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
-              acc[j] = mfma_bf16(ah[s], bo, acc[j]);
-              acc[j] = mfma_bf16(al[s], bh, acc[j]);
+            bh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off0);
+            if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off0);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (s + PRE < KS) {     // stream the weight fragments PRE k-steps ahead
+            wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
+            if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
+          }
+          u32x4 nh[4], no[4];
+          if (s + 1 < KS) {       // next k-step's B fragments in flight during this step's MFMAs
+            const int off = XI::chunk_off(col, 2 * (s + 1) + h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              nh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
+              if (TERMS == 3) no[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
             }
-            acc[j] = mfma_bf16(ah[s], bh, acc[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (TERMS == 3) {
+              acc[j] = mfma_bf16(wh[s % RING], bo[j], acc[j]);
+              acc[j] = mfma_bf16(wl[s % RING], bh[j], acc[j]);
+            }
+            acc[j] = mfma_bf16(wh[s % RING], bh[j], acc[j]);
+          }
+          if (s + 1 < KS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bh[j] = nh[j]; if (TERMS == 3) bo[j] = no[j]; }
           }
         }
       }
@@ -253,25 +294,25 @@ __global__ __launch_bounds__(HP * 2) void fwd_bf16_kernel(FwdArgs a) {
 }
 
 template <int HP>
-static size_t lds_bytes_t() { return XImg<HP>::BYTES + ((size_t)(HP / 32) * 4 * 128 + 4 * 128) * sizeof(float); }
+static size_t lds_bytes_t(int L) { return XImg<HP>::BYTES + ((size_t)(HP / 32) * 4 * 128 + 4 * 128 + (size_t)L * HP) * sizeof(float); }
 
-size_t fwd_bf16_lds_bytes(int HP) {
+size_t fwd_bf16_lds_bytes(int HP, int L) {
   switch (HP) {
-    case 32: return lds_bytes_t<32>(); case 64: return lds_bytes_t<64>(); case 96: return lds_bytes_t<96>();
-    case 128: return lds_bytes_t<128>(); case 160: return lds_bytes_t<160>(); case 192: return lds_bytes_t<192>();
-    case 224: return lds_bytes_t<224>(); default: return lds_bytes_t<256>();
+    case 32: return lds_bytes_t<32>(L); case 64: return lds_bytes_t<64>(L); case 96: return lds_bytes_t<96>(L);
+    case 128: return lds_bytes_t<128>(L); case 160: return lds_bytes_t<160>(L); case 192: return lds_bytes_t<192>(L);
+    case 224: return lds_bytes_t<224>(L); default: return lds_bytes_t<256>(L);
   }
 }
 
 template <int HP, int NS, int TERMS>
 static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
-  size_t lds = lds_bytes_t<HP>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  size_t lds = lds_bytes_t<HP>(a.L);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bf16_kernel<HP, NS, TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL((fwd_bf16_kernel<HP, NS, TERMS>), dim3(grid), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

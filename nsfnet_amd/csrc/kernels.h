@@ -32,6 +32,7 @@ struct FwdArgs {
   float* oadj;           // [4][npad] output adjoints (written when non-null)
   float coef[3];         // oadj_c = coef[c] * (pred_c - tgt_c)
   float* partials;       // [grid][PINN_NLOSS]
+  int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
 };
 
 struct BwdArgs {
@@ -77,7 +78,7 @@ int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_ou
 int launch_fwd_bf16(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
 int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);
 int launch_dw_bf16(int HP, int NS, int terms, const DwArgs& a, hipStream_t s);
-size_t fwd_bf16_lds_bytes(int HP);
+size_t fwd_bf16_lds_bytes(int HP, int L);
 size_t bwd_bf16_lds_bytes(int HP, int L);
 size_t dw_bf16_lds_bytes(int HP);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
