@@ -140,3 +140,54 @@ def test_predict_matches_forward1():
     out, _ = fr.forward1(fr.unflatten(flat.astype(np.float64), 2, 3, L, H), x.astype(np.float32), y.astype(np.float32))
     for mine, ref in ((u, out[:, 0]), (v, out[:, 1]), (p, out[:, 2])):
         np.testing.assert_allclose(mine.cpu().numpy(), ref, rtol=0, atol=3e-6)
+
+
+# ---------------------------------------------------------------------------
+# bf16x3 precision mode (3 bf16 MFMAs per product, fp32 accumulate).  North-star bar:
+# per-step loss within 1e-4 relative of the reference; measured ~4e-7 (loss), <=1.3e-4
+# (pointwise residuals, relative to max|eq|), ~3e-6 (gradient rel-L2).
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("L,H,N,Nb", [(2, 16, 300, 33), (4, 50, 1000, 129), (3, 96, 257, 64), (6, 128, 520, 200),
+                                      (6, 256, 320, 100), (3, 200, 96, 40)])
+@pytest.mark.parametrize("prec", ["bf16x3", ("bf16x3", "fp32", "fp32"), ("fp32", "bf16x3", "bf16x3")])
+def test_bf16x3_mode_meets_parity_bar(L, H, N, Nb, prec):
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    Re, alpha_b, alpha_e = 400.0, 10.0, 1.0
+    flat = _rand_params(3, L, H, seed=100 + H)
+    rng = np.random.RandomState(H + L)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[:: max(1, 2052 // Nb)][:Nb].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=alpha_b, alpha_e=alpha_e, precision=prec)
+    E.net.set_flat(torch.tensor(flat))
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re, alpha_e=alpha_e)
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=alpha_b)
+    for k, name in enumerate(("eq1", "eq2", "eq3")):
+        assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < 5e-4, name
+    np.testing.assert_allclose(E.sums.cpu().numpy()[0:3], r["sums"], rtol=2e-4)
+    ref_loss = alpha_b * sum(b["sums"]) / Nb + alpha_e * sum(r["sums"]) / N
+    assert abs(float(E.loss_terms()["loss"]) - ref_loss) < 1e-4 * ref_loss
+    assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
+
+
+def test_bf16_fast_mode_runs_and_is_close():
+    """Plain bf16 operands: reported-only fast mode (does NOT meet the 1e-4 bar; sanity bound 5 %)."""
+    eng = _engine_mod()
+    L, H, N = 6, 256, 640
+    flat = _rand_params(3, L, H, seed=9)
+    rng = np.random.RandomState(1)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    out = {}
+    for prec in ("fp32", "bf16"):
+        E = eng.PinnEngine(torch.device("cuda:0"), L, H, 2000.0, alpha_b=10.0, alpha_e=1.0, precision=prec)
+        E.net.set_flat(torch.tensor(flat)); E.set_collocation(x, y); E.set_boundary(xb, yb, ub, vb)
+        E.loss_and_grad()
+        out[prec] = (float(E.loss_terms()["loss"]), E.grads.cpu().numpy().astype(np.float64))
+    assert abs(out["bf16"][0] - out["fp32"][0]) < 5e-2 * out["fp32"][0]
+    assert _rel_l2(out["bf16"][1], out["fp32"][1]) < 5e-2

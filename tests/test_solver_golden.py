@@ -199,3 +199,27 @@ def test_ev_train_loop_runs_and_logs(golden_dir, tmp_path, monkeypatch, capsys):
     assert any(f.name.endswith("_evm") for f in d.rglob("*"))
     eu, ev_, ep = P.evaluate(g["x"], g["y"], g["x"] * 0 + 1.0, g["y"] * 0 + 1.0, g["x"] * 0 + 1.0)
     assert np.isfinite([eu, ev_, ep]).all()
+
+
+@pytest.mark.parametrize("name", ["nsfnet_4x50_re100", "nsfnet_6x256_re2000_n256"])
+def test_bf16x3_solver_loss_within_1e4_of_reference(golden_dir, name, tmp_path, monkeypatch):
+    """North-star bar for the bf16 MFMA path: per-step loss within 1e-4 relative of the reference."""
+    from nsfnet_amd import pinn_solver as ps
+    from oracle import autograd_ref as ar
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("NSFNET_PRECISION", "bf16x3")
+    g = _load(golden_dir, name)
+    torch.manual_seed(int(g["seed"]))
+    P = ps.PysicsInformedNeuralNetwork(Re=float(g["Re"]), layers=int(g["L"]), hidden_size=int(g["H"]), N_f=int(g["N"]),
+                                       bc_weight=float(g["alpha_b"]), eq_weight=float(g["alpha_e"]))
+    assert P.engine.net.precision == ("bf16x3",) * 3
+    if "w0" in g.files:
+        P.net.dev_net.set_flat(torch.tensor(g["w0"]))
+    P.set_boundary_data(X=ar.cavity_boundary())
+    P.set_eq_training_data(X=(g["x"], g["y"]))
+    P.save_every = 0
+    for k in range(g["losses"].shape[0]):
+        loss, (loss_e, loss_b) = P.fwd_computing_loss_2d()
+        mine = [loss.item(), loss_b.item(), P.loss_eq1.item(), P.loss_eq2.item(), P.loss_eq3.item()]
+        np.testing.assert_allclose(mine, g["losses"][k], rtol=1e-4)
+        P.engine.adam_step(P.opt.param_groups[0]["lr"])
