@@ -28,7 +28,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X dense f32-input MFMA (MI355X_MICROARCH.md, chip table)
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table): f32-input 157.3 TFLOP/s, bf16 ~2500 TFLOP/s
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
+MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1}
+# HBM bytes per launch of the default workload (6x256, 360k pts) from the PMC passes committed under
+# profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None = not measured.
+PMC_TRAFFIC_BYTES = {}
 
 
 def weight_count(L, H, n_out=3):
@@ -116,8 +121,10 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--grid", type=int, default=600, help="per-GPU collocation grid is grid x grid")
     ap.add_argument("--re", type=float, default=2000.0)
-    ap.add_argument("--precision", default=os.environ.get("NSFNET_PRECISION", "fp32"),
-                    help="fp32 | bf16x3 | bf16 (or fwd,bwd,dw triple)")
+    ap.add_argument("--precision", default=os.environ.get("NSFNET_PRECISION", "bf16x3"),
+                    help="bf16x3 (default: bf16 MFMA, hi/lo split, meets the 1e-4 loss-parity bar) | fp32 "
+                         "(f32-input MFMA, bit-exact fp32) | bf16 (plain bf16 operands, fast mode, no parity claim)")
+    ap.add_argument("--alt-precision", default="fp32", help="second mode reported in the 'alt' block ('' = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=16384)
     args = ap.parse_args()
@@ -129,13 +136,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)      # (rehearsals with more ranks than GPUs share a device)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" IS RCCL on ROCm.  NSFNET_DIST_BACKEND=gloo only exists to rehearse the rank logic on a
+        # box with fewer GPUs than ranks (RCCL refuses two ranks on one device).
+        backend = os.environ.get("NSFNET_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         pg = dist.group.WORLD
 
     from nsfnet_amd import engine as eng
@@ -179,35 +194,66 @@ def main():
     loss = float(E.loss_terms()["loss"])
     log("timed region done: %.2f ms/step, loss %.6f" % (1e3 * dt / args.steps, loss))
 
-    if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        value = n_global * args.steps / dt
-        # ---- per-kernel timing of the three MFMA kernels (outside the timed region) ----
-        f = E.plan_f
+    def kernel_report(E_, prec, ms_step):
+        f = E_.plan_f
         c = 2.0 / n_global
         reps = max(3, min(10, args.steps))
         t_fwd = time_kernel(lambda: f.forward(Re, save=True), reps)
         t_bwd = time_kernel(lambda: f.backward(Re, (c, c, c, 0.0), phases=1), reps)
         t_dw = time_kernel(lambda: f.backward(Re, (c, c, c, 0.0), phases=2), reps)
-        log("kernel ms: fwd %.3f bwd %.3f dw %.3f" % (t_fwd, t_bwd, t_dw))
+        log("[%s] kernel ms: fwd %.3f bwd %.3f dw %.3f" % (prec, t_fwd, t_bwd, t_dw))
         pw = weight_count(L, H)
         flops_each = 8.0 * pw * n_local        # fwd, dX sweep and dW GEMM each carry 2*4*P_w FLOP per point
-        kernels = {"fwd_kernel": t_fwd, "bwd_kernel": t_bwd, "dw_kernel": t_dw}
+        names = {"fp32": ("fwd_kernel", "bwd_kernel", "dw_kernel"),
+                 "bf16x3": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel"),
+                 "bf16": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel")}[prec]
+        kernels = dict(zip(names, (t_fwd, t_bwd, t_dw)))
         dom = max(kernels, key=kernels.get)
         achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel=dom, achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                        kernel_ms={k: round(v, 4) for k, v in kernels.items()},
-                        step_tflops=24.0 * pw * n_local / (ms_per_step * 1e-3) / 1e12)
+        peak = MFMA_PEAK_TFLOPS[prec]
+        traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid) == (6, 256, 600) else None
+        return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
+                    traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[prec],
+                    mfma_issue_frac=achieved * MFMA_PER_PRODUCT[prec] / peak,
+                    kernel_ms={k: round(v, 4) for k, v in kernels.items()},
+                    step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = n_global * args.steps / dt
+        # ---- per-kernel timing of the three MFMA kernels (outside the timed region) ----
+        prec = args.precision if args.precision in MFMA_PEAK_TFLOPS else "fp32"
+        roofline = kernel_report(E, prec, ms_per_step)
         out = dict(metric="collocation-pt NS-residual evals/sec, Re=2000 6x256 MLP",
                    value=value, unit="collocation-pt residual evals/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="f32", data="synthetic",
+                   vs_baseline=None, dtype={"fp32": "f32", "bf16x3": "bf16x3 (bf16 MFMA, hi/lo split, f32 accumulate)",
+                                            "bf16": "bf16"}.get(prec, prec), data="synthetic",
                    config=dict(workload="Re=%g cavity, %dx%d tanh FCNet, %d collocation pts/GPU (%dx%d cell-centred "
-                                        "uniform grid) + 2052 BC pts, full Adam step, fp32 MFMA"
-                                        % (Re, L, H, n_local, args.grid, args.grid),
+                                        "uniform grid) + 2052 BC pts, full Adam step, precision %s"
+                                        % (Re, L, H, n_local, args.grid, args.grid, args.precision),
                                global_points=n_global, parallelism="dp%d" % world, final_loss=loss),
                    roofline=roofline)
+        if args.alt_precision and args.alt_precision != args.precision and world == 1:
+            del E
+            torch.cuda.empty_cache()
+            E2 = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, precision=args.alt_precision)
+            E2.net.set_flat(seeded_flat(L, H))
+            E2.set_collocation(x, y, n_global=n_global)
+            E2.set_boundary(xb[lo:hi], yb[lo:hi], ub[lo:hi], vb[lo:hi], n_global=nb)
+            for _ in range(2):
+                E2.step(lr)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k2 = max(3, args.steps // 2)
+            for _ in range(k2):
+                E2.step(lr)
+            torch.cuda.synchronize()
+            ms2 = 1e3 * (time.perf_counter() - t1) / k2
+            out["alt"] = dict(precision=args.alt_precision, value=n_global / (ms2 * 1e-3), ms_per_step=ms2, steps=k2,
+                              roofline=kernel_report(E2, args.alt_precision, ms2))
+            del E2
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(L, H, Re, args.cpu_sample)
         elif world > 1:
