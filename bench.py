@@ -33,7 +33,10 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1}
 # HBM bytes per launch of the default workload (6x256, 360k pts) from the PMC passes committed under
 # profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None = not measured.
-PMC_TRAFFIC_BYTES = {}
+PMC_TRAFFIC_BYTES = {   # profiles/r01_v2_bf16x3_pmc_summary.txt, profiles/r01_v1_fp32_pmc_summary.txt
+    ("bf16x3", "fwd_bf16_kernel"): 9.336e9, ("bf16x3", "bwd_bf16_kernel"): 1.680e10, ("bf16x3", "dw_bf16_kernel"): 1.481e10,
+    ("fp32", "fwd_kernel"): 9.363e9, ("fp32", "bwd_kernel"): 1.684e10, ("fp32", "dw_kernel"): 1.481e10,
+}
 
 
 def weight_count(L, H, n_out=3):
