@@ -213,6 +213,27 @@ def gen_ev_freeze(mods, name, seed=7):
           " 10001->10002 =", np.abs(snaps["pe_10002"] - snaps["pe_10001"]).max())
 
 
+def gen_data_prep(ns, ev):
+    """Reference sampler under a seeded global RNG (tools.py:30-83) and SDF weights
+    (ev-NSFnet/cavity_data.py:118-130)."""
+    import types
+    tools = sys.modules.get("tools")
+    dl = ns["cavity_data"].DataLoader(N_f=600)
+    bc = dl.loading_boundary_data()
+    np.random.seed(123)
+    x, y = dl.loading_training_data()           # LHSample + sort_pts, reference code
+    np.random.seed(321)
+    lhs = ns["cavity_data"].LHSample(2, [[0.0, 1.0], [-1.0, 1.0]], 257)
+    cfg = types.SimpleNamespace(enabled=True, min_weight=0.3, decay=4.0)
+    dle = ev["cavity_data"].DataLoader(N_f=400, sort_training_points=False, sdf_weighting=cfg, coord_transform=True)
+    dle.loading_boundary_data()
+    np.random.seed(77)
+    xe, ye = dle.loading_training_data()
+    np.savez_compressed(os.path.join(OUT, "data_prep.npz"), x_sorted=x, y_sorted=y, lhs=lhs,
+                        xe=xe, ye=ye, sdf=dle.get_sdf_weights(), coord_scale=dle.get_coord_scale())
+    print("data_prep done", x.shape, lhs.shape, xe.shape)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -226,6 +247,7 @@ def main():
         gen_ev(ev, "ev_4x50_4x40_re4000", 4, 50, 4, 40, 1024, 4000, 0.05, 11, 4)
         gen_ev(ev, "ev_2x16_sdf_scaled", 2, 16, 2, 12, 256, 3000, 0.03, 21, 4, sdf=True, coord_scale=2.0)
         gen_ev_freeze(ev, "ev_freeze_2x8")
+        gen_data_prep(ns, ev)
         os.chdir("/tmp")
 
 

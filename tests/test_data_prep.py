@@ -1,0 +1,57 @@
+"""Vectorised sampler / sorter / SDF weights vs vectors produced by the reference's own
+tools.py / cavity_data.py under a seeded global numpy RNG (tests/golden/data_prep.npz,
+oracle/gen_golden.py::gen_data_prep).  Bit-exact: same RNG stream, same IEEE operations."""
+import os
+import types
+
+import numpy as np
+
+from nsfnet_amd import cavity_data, tools
+
+
+def test_lhs_sort_and_sdf_match_reference(golden_dir, capsys):
+    g = np.load(os.path.join(golden_dir, "data_prep.npz"))
+    dl = cavity_data.DataLoader(N_f=600)
+    dl.loading_boundary_data()
+    np.random.seed(123)
+    x, y = dl.loading_training_data()
+    np.testing.assert_array_equal(x, g["x_sorted"])
+    np.testing.assert_array_equal(y, g["y_sorted"])
+    np.random.seed(321)
+    np.testing.assert_array_equal(tools.LHSample(2, [[0.0, 1.0], [-1.0, 1.0]], 257), g["lhs"])
+    cfg = types.SimpleNamespace(enabled=True, min_weight=0.3, decay=4.0)
+    dle = cavity_data.EvDataLoader(N_f=400, sort_training_points=False, sdf_weighting=cfg, coord_transform=True)
+    dle.loading_boundary_data()
+    np.random.seed(77)
+    xe, ye = dle.loading_training_data()
+    np.testing.assert_array_equal(xe, g["xe"])
+    np.testing.assert_array_equal(ye, g["ye"])
+    np.testing.assert_array_equal(dle.get_sdf_weights(), g["sdf"])
+    assert dle.get_coord_scale() == float(g["coord_scale"]) == 2.0
+    capsys.readouterr()
+
+
+def test_sort_is_by_wall_distance_and_handles_large_sets():
+    rng = np.random.RandomState(0)
+    pts = rng.rand(20000, 2)
+    dl = cavity_data.DataLoader(N_f=10)
+    dl.loading_boundary_data()
+    sorted_pts, d = tools.sort_pts(pts, dl.pts_bc)
+    assert sorted_pts.shape == (20000, 2) and d.shape == (20000, 1)
+    assert np.all(np.diff(d[:, 0]) >= 0)
+    # distance to the discrete 513-per-side wall set is within half a wall spacing of the analytic wall distance
+    wall = np.minimum.reduce([sorted_pts[:, 0], 1 - sorted_pts[:, 0], sorted_pts[:, 1], 1 - sorted_pts[:, 1]])
+    assert np.abs(d[:, 0] - wall).max() < 1.0 / 512
+
+
+def test_evaluate_data_loader_shapes(tmp_path):
+    import scipy.io
+    n = 5
+    X, Y = np.meshgrid(np.linspace(0, 1, n), np.linspace(0, 1, n))
+    P = np.ones((n, n)); P[0, 0] = np.nan
+    f = str(tmp_path / "ref.mat")
+    scipy.io.savemat(f, dict(X_ref=X, Y_ref=Y, U_ref=X * 2, V_ref=Y * 3, P_ref=P))
+    x, y, u, v = cavity_data.DataLoader().loading_evaluate_data(f)
+    assert x.shape == (n * n, 1) and np.allclose(u, 2 * x)
+    out = cavity_data.EvDataLoader(coord_transform=True).loading_evaluate_data(f)
+    assert len(out) == 5 and np.isnan(out[4]).sum() == 1 and out[0].min() == -1.0
