@@ -65,7 +65,7 @@ int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out)
   if (!out) return fail(-22, "pinn_net_create: null out%s");
   if (n_out < 1 || n_out > 3) return fail(-22, "pinn_net_create: n_out must be 1..3%s");
   if (n_hidden_layers < 1 || n_hidden_layers > 64) return fail(-22, "pinn_net_create: hidden layers must be 1..64%s");
-  if (hidden < 1 || hidden > PINN_MAX_HP) return fail(-22, "pinn_net_create: hidden width must be 1..256 (got %s%ld)", "", hidden);
+  if (hidden < 1 || hidden > PINN_MAX_HP) return fail(-22, "pinn_net_create: hidden width must be 1..512 (got %s%ld)", "", hidden);
   pinn_net_s* n = new (std::nothrow) pinn_net_s;
   if (!n) return fail(-12, "pinn_net_create: out of host memory%s");
   n->n_out = n_out; n->L = n_hidden_layers; n->H = hidden; n->HP = (hidden + 31) / 32 * 32;
@@ -77,6 +77,8 @@ int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_
   if (!net) return fail(-22, "pinn_net_set_precision: null net%s");
   if (prec_fwd < 0 || prec_fwd > 2 || prec_bwd < 0 || prec_bwd > 2 || prec_dw < 0 || prec_dw > 2)
     return fail(-22, "pinn_net_set_precision: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16)%s");
+  if (net->HP > 256 && (prec_fwd || prec_bwd || prec_dw))
+    return fail(-22, "pinn_net_set_precision: the bf16 modes support hidden <= 256; wider nets run the fp32 MFMA path%s");
   net->prec_fwd = prec_fwd; net->prec_bwd = prec_bwd; net->prec_dw = prec_dw;
   return 0;
 }
@@ -99,7 +101,8 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (!p) return fail(-12, "pinn_plan_create: out of host memory%s");
   p->net = *net;
   p->n = n_points; p->streams = streams;
-  const int per_tile = streams == 4 ? 32 : 128;
+  const bool wide = net->HP > 256;
+  const int per_tile = wide ? (streams == 4 ? 16 : 64) : (streams == 4 ? 32 : 128);
   p->ntiles = (int)((n_points + per_tile - 1) / per_tile);
   p->npad = p->ntiles * per_tile;
   const int HP = net->HP, L = net->L, NW = HP / 32;
@@ -110,9 +113,10 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     if (b > bw) b = bw;
     return b < 1 ? 1 : b;
   };
-  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP, L) : fwd_lds_bytes(HP);
-  const size_t lds_b = net->prec_bwd ? bwd_bf16_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
-  const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : dw_lds_bytes(HP);
+  const size_t lds_f = wide ? fwd_wide_lds_bytes(HP) : net->prec_fwd ? fwd_bf16_lds_bytes(HP, L) : fwd_lds_bytes(HP);
+  const size_t lds_b = wide ? bwd_wide_lds_bytes(HP, L) : net->prec_bwd ? bwd_bf16_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
+  const size_t lds_d = wide ? dw_wide_lds_bytes() : net->prec_dw ? dw_bf16_lds_bytes(HP) : dw_lds_bytes(HP);
+  if (lds_b > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
   p->grid_b = cus * bpc(lds_b);
@@ -131,8 +135,9 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   p->bytes_fwd = off;
   p->off_sg = off;       off = align_up(off + (size_t)p->grid_b * sg_total(HP, L) * 4, 256);
   p->off_slabs = off;    off = align_up(off + (size_t)(L - 1) * p->groups * HP * HP * 4, 256);
-  p->off_S = off;        off = align_up(off + (size_t)p->ntiles * L * act_block(HP) * 4, 256);
-  p->off_Zb = off;       off = align_up(off + (size_t)p->ntiles * L * act_block(HP) * 4, 256);
+  const size_t ablk = (size_t)HP * (wide ? 64 : PINN_TILE_COLS);
+  p->off_S = off;        off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
+  p->off_Zb = off;       off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
   p->bytes_all = off;
   *out = p;
   return 0;
@@ -162,8 +167,9 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 1) : 0;
-  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                              : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
+  int rc = plan->net.HP > 256 ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
+           : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                                : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -177,6 +183,7 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
+  if (plan->net.HP > 256) return launch_dw_wide(plan->net.HP, plan->streams, d, s);
   return plan->net.prec_dw ? launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s)
                            : launch_dw(plan->net.HP, plan->streams, d, s);
 }
@@ -197,8 +204,9 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {
-    rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                            : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+    rc = plan->net.HP > 256 ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
+         : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                              : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
   }
   if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
@@ -231,8 +239,9 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = save ? WS(plan, off_oadj) : nullptr;
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
-  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                              : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
+  int rc = plan->net.HP > 256 ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
+           : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                                : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -252,8 +261,9 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
-  int rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                              : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
+  int rc = plan->net.HP > 256 ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
+           : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                                : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");
   rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;

@@ -74,6 +74,13 @@ int dw_threads(int HP);
 
 int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_out, int prec_fwd, int prec_bwd,
                 hipStream_t s);
+// wide nets (256 < HP <= 512): 64-column tiles, fp32 MFMA only
+int launch_fwd_wide(int HP, int NS, const FwdArgs& a, int grid, hipStream_t s);
+int launch_bwd_wide(int HP, int NS, const BwdArgs& a, int grid, hipStream_t s);
+int launch_dw_wide(int HP, int NS, const DwArgs& a, hipStream_t s);
+size_t fwd_wide_lds_bytes(int HP);
+size_t bwd_wide_lds_bytes(int HP, int L);
+size_t dw_wide_lds_bytes();
 // bf16 MFMA variants (terms = 3: bf16x3 split, terms = 1: plain bf16)
 int launch_fwd_bf16(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
 int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);

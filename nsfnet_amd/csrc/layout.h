@@ -23,7 +23,7 @@
 #endif
 
 #define PINN_TILE_COLS 128
-#define PINN_MAX_HP 256
+#define PINN_MAX_HP 512      // <= 256: 128-column tiles (all precisions); 257..512: 64-column tiles (fp32)
 #define PINN_NLOSS 8   // loss partial slots per workgroup
 
 // ---- prepared-parameter buffer (floats) -----------------------------------

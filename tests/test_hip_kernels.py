@@ -37,6 +37,8 @@ def _rand_params(n_out, L, H, seed):
 CASES = [  # (L, H, N, Nb)   H=50 / 40 exercise the zero padding to 64, N not a tile multiple
     (1, 8, 37, 5), (2, 16, 300, 33), (4, 50, 1000, 129), (3, 96, 257, 64), (6, 128, 520, 200), (6, 256, 320, 100),
     (3, 200, 96, 40),
+    # wide nets (64-column tiles, permlane16 stream exchange, blocked dW): BASELINE config 5 is 8x400
+    (2, 300, 70, 30), (3, 400, 150, 70), (2, 512, 40, 64),
 ]
 
 
