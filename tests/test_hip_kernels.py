@@ -193,3 +193,36 @@ def test_bf16_fast_mode_runs_and_is_close():
         out[prec] = (float(E.loss_terms()["loss"]), E.grads.cpu().numpy().astype(np.float64))
     assert abs(out["bf16"][0] - out["fp32"][0]) < 5e-2 * out["fp32"][0]
     assert _rel_l2(out["bf16"][1], out["fp32"][1]) < 5e-2
+
+
+def test_config5_shape_ev_8x400_with_4x40_entropy_net():
+    """BASELINE config 5 shape (ev-NSFnet Re=10000, 8x400 main net + 4x40 entropy net) at a
+    test-sized point count, entropy net trainable, vs the fp64 oracle."""
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    L, H, L1, H1, N, Re = 8, 400, 4, 40, 200, 10000.0
+    flat = _rand_params(3, L, H, seed=15); flat_e = _rand_params(1, L1, H1, seed=16)
+    rng = np.random.RandomState(8)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::32].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, flavour="ev", n_hidden_e=L1, hidden_e=H1,
+                       alpha_evm=0.05)
+    E.net.set_flat(torch.tensor(flat)); E.net_e.set_flat(torch.tensor(flat_e))
+    E.e_trainable = True
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    vtm0 = E.plan_f.vis_t_minus.cpu().numpy().astype(np.float64)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    Pe = fr.unflatten(flat_e.astype(np.float64), 2, 1, L1, H1)
+    e, saved_e = fr.forward1(Pe, x.astype(np.float64), y.astype(np.float64))
+    vis_t = np.minimum(np.float32(20.0 / Re), vtm0)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re, vis_t=vis_t, e=e[:, 0])
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    for k, name in enumerate(("eq1", "eq2", "eq3", "eq4")):
+        assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < 5e-5, name
+    np.testing.assert_allclose(E.sums.cpu().numpy()[0:4], r["sums"], rtol=2e-5)
+    assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
+    ge = fr.backward1(Pe, x.astype(np.float64), y.astype(np.float64), saved_e, r["e_adj"].reshape(-1, 1))
+    assert _rel_l2(E.grads_e.cpu().numpy(), ge) < 1e-4
