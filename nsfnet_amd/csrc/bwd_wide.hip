@@ -283,7 +283,7 @@ static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
 
 int launch_bwd_wide(int HP, int NS, const BwdArgs& a, int grid, hipStream_t s) {
   switch (HP) {
-    BWD_CASE(288) BWD_CASE(320) BWD_CASE(352) BWD_CASE(384)
+    BWD_CASE(128) BWD_CASE(256) BWD_CASE(288) BWD_CASE(320) BWD_CASE(352) BWD_CASE(384)
     BWD_CASE(416) BWD_CASE(448) BWD_CASE(480) BWD_CASE(512)
     default: return -1000;
   }

@@ -24,9 +24,18 @@ static int hipfail(int rc, const char* what) {
 // precision of a kernel family: 0 = fp32-input MFMA (exact fp32), 1 = bf16x3 split, 2 = plain bf16
 struct pinn_net_s {
   int n_out, L, H, HP;
+  int wide;   // 64-column tile kernels (always for HP > 256; PINN_FORCE_WIDE=1 forces them for HP 128/256)
   int prec_fwd, prec_bwd, prec_dw;
 };
 static int terms_of(int prec) { return prec == 1 ? 3 : 1; }
+// 64-column-tile kernels: always for HP > 256; for HP == 256 in fp32 mode they are also the faster
+// choice (two workgroups per CU overlap each other's epilogue and MFMA phases): PINN_FORCE_WIDE=0 opts out.
+static int env_int(const char* name, int dflt);
+static int pick_wide(const pinn_net_s* n) {
+  if (n->HP > 256) return 1;
+  const bool fp32 = !n->prec_fwd && !n->prec_bwd && !n->prec_dw;
+  return fp32 && n->HP == 256 && env_int("PINN_FORCE_WIDE", 1) != 0;
+}
 
 struct pinn_plan_s {
   pinn_net_s net;
@@ -54,7 +63,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
-}
+}  // (declared above pick_wide)
 
 extern "C" {
 
@@ -70,6 +79,7 @@ int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out)
   if (!n) return fail(-12, "pinn_net_create: out of host memory%s");
   n->n_out = n_out; n->L = n_hidden_layers; n->H = hidden; n->HP = (hidden + 31) / 32 * 32;
   n->prec_fwd = n->prec_bwd = n->prec_dw = 0;
+  n->wide = pick_wide(n);
   *out = n;
   return 0;
 }
@@ -80,6 +90,7 @@ int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_
   if (net->HP > 256 && (prec_fwd || prec_bwd || prec_dw))
     return fail(-22, "pinn_net_set_precision: the bf16 modes support hidden <= 256; wider nets run the fp32 MFMA path%s");
   net->prec_fwd = prec_fwd; net->prec_bwd = prec_bwd; net->prec_dw = prec_dw;
+  net->wide = pick_wide(net);
   return 0;
 }
 int pinn_net_destroy(pinn_net_t net) { delete net; return 0; }
@@ -101,7 +112,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (!p) return fail(-12, "pinn_plan_create: out of host memory%s");
   p->net = *net;
   p->n = n_points; p->streams = streams;
-  const bool wide = net->HP > 256;
+  const bool wide = net->wide != 0;
   const int per_tile = wide ? (streams == 4 ? 16 : 64) : (streams == 4 ? 32 : 128);
   p->ntiles = (int)((n_points + per_tile - 1) / per_tile);
   p->npad = p->ntiles * per_tile;
@@ -109,7 +120,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   const int cus = num_cus();
   auto bpc = [&](size_t lds) {
     int b = (int)(163840 / lds);
-    int bw = NW >= 8 ? 1 : 8 / NW;
+    int bw = NW >= 8 ? (wide && NW == 8 ? 2 : 1) : 8 / NW;
     if (b > bw) b = bw;
     return b < 1 ? 1 : b;
   };
@@ -167,7 +178,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 1) : 0;
-  int rc = plan->net.HP > 256 ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
+  int rc = plan->net.wide ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
            : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
                                 : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
@@ -183,7 +194,7 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
-  if (plan->net.HP > 256) return launch_dw_wide(plan->net.HP, plan->streams, d, s);
+  if (plan->net.wide) return launch_dw_wide(plan->net.HP, plan->streams, d, s);
   return plan->net.prec_dw ? launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s)
                            : launch_dw(plan->net.HP, plan->streams, d, s);
 }
@@ -204,7 +215,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {
-    rc = plan->net.HP > 256 ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
+    rc = plan->net.wide ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
          : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
                               : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
@@ -239,7 +250,7 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = save ? WS(plan, off_oadj) : nullptr;
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
-  int rc = plan->net.HP > 256 ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
+  int rc = plan->net.wide ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
            : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
                                 : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
@@ -261,7 +272,7 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
-  int rc = plan->net.HP > 256 ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
+  int rc = plan->net.wide ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
            : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
                                 : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");

@@ -258,7 +258,7 @@ static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
 
 int launch_fwd_wide(int HP, int NS, const FwdArgs& a, int grid, hipStream_t s) {
   switch (HP) {
-    FWD_CASE(288) FWD_CASE(320) FWD_CASE(352) FWD_CASE(384)
+    FWD_CASE(128) FWD_CASE(256) FWD_CASE(288) FWD_CASE(320) FWD_CASE(352) FWD_CASE(384)
     FWD_CASE(416) FWD_CASE(448) FWD_CASE(480) FWD_CASE(512)
     default: return -1000;
   }
