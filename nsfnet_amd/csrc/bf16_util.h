@@ -42,16 +42,16 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 // ---- activation image in LDS for the fused fwd/bwd kernels -------------------
-// X[hilo(2)][plane j(4)][col(32)][k (RSE)] bf16, RSE = HP rounded up to a power of two
+// X[hilo(2)][plane(4)][col in plane (PPL)][k (RSE)] bf16, RSE = HP rounded up to a power of two
 // (>= 32); 16-byte chunks (8 k) XOR-swizzled so that the ds_read_b128 of one k-chunk by
-// 32 different columns is bank-conflict free.
-template <int HP>
+// different columns is bank-conflict free.  PPL = 32 (128-column tile) or 16 (64-column tile).
+template <int HP, int PPL = 32>
 struct XImg {
   static constexpr int RSE = HP <= 32 ? 32 : HP <= 64 ? 64 : HP <= 128 ? 128 : 256;
   static constexpr int NCH = RSE / 8;                    // chunks per row
   static constexpr int R = RSE >= 128 ? 1 : 128 / RSE;   // rows per 256-byte bank row
   static constexpr int MASK = (NCH < 16 ? NCH : 16) - 1;
-  static constexpr int PLANE = 32 * RSE;                 // elements per (hilo, j) plane
+  static constexpr int PLANE = PPL * RSE;                // elements per (hilo, plane)
   static constexpr int HALF = 4 * PLANE;                 // elements per hilo half
   static constexpr size_t BYTES = (size_t)2 * HALF * 2;
   // byte offset (within one plane) of chunk `ch` of column `col`

@@ -2,12 +2,14 @@
 // and the reference lines it replaces: loss.backward(), NSFnet/pinn_solver.py:252,
 // ev-NSFnet/pinn_solver.py:469).  G_{l-1} = W_l^T Zb_l runs on v_mfma_f32_32x32x16_bf16 with
 // hi/lo split operands (bf16_util.h); the z-adjoint tile lives in LDS as
-// X[hi|lo][stream][col][k] bf16 (swizzled); Zb spilled to HBM stays fp32 (layout.h).
+// X[hi|lo][plane][col][k] bf16 (swizzled); Zb spilled to HBM stays fp32 (layout.h).
+// COLS = 128 / 64: tile geometry as in fwd_bf16.hip.
 #include "kernels.h"
 #include "bf16_util.h"
 
-__device__ __forceinline__ float red32(float v) {
-  v += __shfl_xor(v, 16);
+template <int W>
+__device__ __forceinline__ float red_cols(float v) {   // sum over the W (16 or 32) lanes that share a feature
+  if (W == 32) v += __shfl_xor(v, 16);
   v += __shfl_xor(v, 8);
   v += __shfl_xor(v, 4);
   v += __shfl_xor(v, 2);
@@ -15,21 +17,25 @@ __device__ __forceinline__ float red32(float v) {
   return v;
 }
 
-template <int HP, int NS, int TERMS>
+template <int HP, int NS, int TERMS, int COLS>
 __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
-  using XI = XImg<HP>;
+  constexpr int PPL = COLS / 4, NTL = COLS / 32;
+  using XI = XImg<HP, PPL>;
   constexpr int NT = HP * 2, KS = HP / 16;
-  constexpr int PRE = KS < 4 ? KS : 4, RING = (PRE + 2 < KS) ? PRE + 2 : KS;
+  constexpr int PRE = COLS == 64 ? (KS < 2 ? KS : 2) : (KS < 4 ? KS : 4);
+  constexpr int RING = (PRE + 2 < KS) ? PRE + 2 : KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char* Xb = ldsb;                                       // [2][4][32][RSE] bf16
-  float* oadjL = reinterpret_cast<float*>(ldsb + XI::BYTES);      // [4][128]
-  float* sgacc = oadjL + 4 * 128;                                 // [sg_total]
+  unsigned char* Xb = ldsb;                                       // [2][4][PPL][RSE] bf16
+  float* oadjL = reinterpret_cast<float*>(ldsb + XI::BYTES);      // [4][COLS]
+  float* sgacc = oadjL + 4 * COLS;                                // [sg_total]
   const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int hi = COLS == 64 ? (col >> 4) : 0;
+  const int pp = COLS == 64 ? (col & 15) : col;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ob = w * 32;
   const float* __restrict__ P = a.prep;
   const int L = a.L;
-  const int npad = a.ntiles * (NS == 4 ? 32 : 128);
+  const int npad = a.ntiles * (NS == 4 ? PPL : COLS);
   const int SG = sg_total(HP, L);
   for (int i = tid; i < SG; i += NT) sgacc[i] = 0.f;
   float dbo[3] = {0.f, 0.f, 0.f};
@@ -37,13 +43,13 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     // ---------------- output adjoints per column ----------------
-    float px[4], py[4];
+    float px[NTL], py[NTL];
     if (NS == 4) {
-      const int ptc = tile * 32 + col;
+      const int ptc = tile * PPL + pp;
       px[0] = ptc < a.n ? a.x[ptc] : 0.f;
       py[0] = ptc < a.n ? a.y[ptc] : 0.f;
-      if (tid < 32) {
-        const int pt = tile * 32 + tid;
+      if (tid < PPL) {
+        const int pt = tile * PPL + tid;
         const bool m = pt < a.n;
         const float* f = a.fld + pt;
         float u = f[FLD_U * (size_t)npad], v = f[FLD_V * (size_t)npad];
@@ -59,44 +65,48 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
         const float sc = a.scale, sc2 = a.scale * a.scale;
         float au = r1 * ux + r2 * vx + g4 * eq1;
         float av = r1 * uy + r2 * vy + g4 * eq2;
-        oadjL[0 * 128 + 0 + tid] = au;
-        oadjL[0 * 128 + 32 + tid] = (r1 * u + r3) * sc;
-        oadjL[0 * 128 + 64 + tid] = (r1 * v) * sc;
-        oadjL[0 * 128 + 96 + tid] = -nu * r1 * sc2;
-        oadjL[1 * 128 + 0 + tid] = av;
-        oadjL[1 * 128 + 32 + tid] = (r2 * u) * sc;
-        oadjL[1 * 128 + 64 + tid] = (r2 * v + r3) * sc;
-        oadjL[1 * 128 + 96 + tid] = -nu * r2 * sc2;
-        oadjL[2 * 128 + 0 + tid] = 0.f;
-        oadjL[2 * 128 + 32 + tid] = r1 * sc;
-        oadjL[2 * 128 + 64 + tid] = r2 * sc;
-        oadjL[2 * 128 + 96 + tid] = 0.f;
+        oadjL[0 * COLS + 0 * PPL + tid] = au;
+        oadjL[0 * COLS + 1 * PPL + tid] = (r1 * u + r3) * sc;
+        oadjL[0 * COLS + 2 * PPL + tid] = (r1 * v) * sc;
+        oadjL[0 * COLS + 3 * PPL + tid] = -nu * r1 * sc2;
+        oadjL[1 * COLS + 0 * PPL + tid] = av;
+        oadjL[1 * COLS + 1 * PPL + tid] = (r2 * u) * sc;
+        oadjL[1 * COLS + 2 * PPL + tid] = (r2 * v + r3) * sc;
+        oadjL[1 * COLS + 3 * PPL + tid] = -nu * r2 * sc2;
+        oadjL[2 * COLS + 0 * PPL + tid] = 0.f;
+        oadjL[2 * COLS + 1 * PPL + tid] = r1 * sc;
+        oadjL[2 * COLS + 2 * PPL + tid] = r2 * sc;
+        oadjL[2 * COLS + 3 * PPL + tid] = 0.f;
         if (a.ebar && m) a.ebar[pt] = -g4;
         dbo[0] += au; dbo[1] += av;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int pt = tile * 128 + 32 * j + col;
+      for (int j = 0; j < NTL; ++j) {
+        int pt = tile * COLS + 32 * j + col;
         px[j] = pt < a.n ? a.x[pt] : 0.f;
         py[j] = pt < a.n ? a.y[pt] : 0.f;
       }
-      for (int idx = tid; idx < 3 * 128; idx += NT) {
-        int c = idx >> 7, cc = idx & 127;
-        int pt = tile * 128 + cc;
-        float v = (c < a.n_out && pt < a.n) ? a.oadj[(size_t)c * npad + pt] : 0.f;
+      for (int idx = tid; idx < 3 * COLS; idx += NT) {
+        int c3 = idx / COLS, cc = idx % COLS;
+        int pt = tile * COLS + cc;
+        float v = (c3 < a.n_out && pt < a.n) ? a.oadj[(size_t)c3 * npad + pt] : 0.f;
         oadjL[idx] = v;
-        if (c == 0) dbo[0] += v; else if (c == 1) dbo[1] += v; else dbo[2] += v;
+        if (c3 == 0) dbo[0] += v; else if (c3 == 1) dbo[1] += v; else dbo[2] += v;
       }
     }
     __syncthreads();
-    // ---------------- adjoint of the last hidden layer's activations (3 -> HP, rank-3) ----------------
-    f32x16 acc[4];
-    float oa[3][4];
+    // ---------------- adjoint of the last hidden layer's activations (rank-3 update) ----------------
+    f32x16 acc[NTL];
+    float oc[3][NTL];   // output adjoints of this lane's column in accumulator tile j
+    float oa[3][4];     // residual mode: the four streams of this lane's point (output-layer dW)
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c3 = 0; c3 < 3; ++c3) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) oa[c][j] = oadjL[c * 128 + 32 * j + col];
+      for (int j = 0; j < NTL; ++j) oc[c3][j] = oadjL[c3 * COLS + 32 * j + col];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) oa[c3][s] = oadjL[c3 * COLS + s * PPL + pp];
+    }
     {
       const float* wo = P + prep_wout(HP, L);
 #pragma unroll
@@ -104,11 +114,12 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
         const int o = ob + mfma_row(r, h);
         float w0 = wo[o], w1 = wo[HP + o], w2 = wo[2 * HP + o];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j][r] = w0 * oa[0][j] + w1 * oa[1][j] + w2 * oa[2][j];
+        for (int j = 0; j < NTL; ++j) acc[j][r] = w0 * oc[0][j] + w1 * oc[1][j] + w2 * oc[2][j];
       }
     }
     for (int l = L - 1; l >= 0; --l) {
-      // W_l^T fragments are requested before this layer's Zb stores (in-order vmcnt, see fwd_bf16.hip)
+      // W_l^T fragments: the first PRE k-steps are requested before this layer's Zb stores
+      // (vmcnt retires in order), the rest stream through the register ring in the MFMA loop
       u32x4 wh[RING], wl[RING];
       const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l > 0 ? l : 1)) + (size_t)w * KS * 64 + lane;
       if (l > 0) {
@@ -119,86 +130,144 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
         }
       }
       asm volatile("" ::: "memory");
-      const float* Sl = a.S + ((size_t)tile * L + l) * act_block(HP);
-      float* Zl = a.Zb + ((size_t)tile * L + l) * act_block(HP);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-        f32x4 s0 = Sg[0 * (HP / 4) * 32], s1 = Sg[1 * (HP / 4) * 32];
-        f32x4 s2 = Sg[2 * (HP / 4) * 32], s3 = Sg[3 * (HP / 4) * 32];
+      const float* Sl = a.S + ((size_t)tile * L + l) * ((size_t)HP * COLS);
+      float* Zl = a.Zb + ((size_t)tile * L + l) * ((size_t)HP * COLS);
+
+      // residual mode: tanh adjoint of one register quad (features ob+8g+4h+e, column pp), all streams
+      auto adj_quad = [&](int g, const f32x4& ga, const f32x4& gx, const f32x4& gy, const f32x4& gd) {
+        const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
+        f32x4 s0 = Sg[0 * (HP / 4) * PPL], s1 = Sg[1 * (HP / 4) * PPL];
+        f32x4 s2 = Sg[2 * (HP / 4) * PPL], s3 = Sg[3 * (HP / 4) * PPL];
         f32x4 z0, z1, z2, z3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
           const int o = ob + 8 * g + 4 * h + e;
-          float zb, dbv, dwx, dwy;
+          float t = s0[e], zx = s1[e], zy = s2[e], zd = s3[e];
+          float d1 = 1.f - t * t;
+          float d2 = -2.f * t * d1;
+          float d3 = -2.f * d1 * (1.f - 3.f * t * t);
           float wo0 = 0.f, wo1 = 0.f, wo2 = 0.f;
-          if (NS == 4) {
-            float t = s0[e], zx = s1[e], zy = s2[e], zd = s3[e];
-            float d1 = 1.f - t * t;
-            float d2 = -2.f * t * d1;
-            float d3 = -2.f * d1 * (1.f - 3.f * t * t);
-            float ga = acc[0][r], gx = acc[1][r], gy = acc[2][r], gd = acc[3][r];
-            if (l == L - 1) {   // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
-              float ax = d1 * zx, ay = d1 * zy, ad = d2 * (zx * zx + zy * zy) + d1 * zd;
-              wo0 = oa[0][0] * t + oa[0][1] * ax + oa[0][2] * ay + oa[0][3] * ad;
-              wo1 = oa[1][0] * t + oa[1][1] * ax + oa[1][2] * ay + oa[1][3] * ad;
-              wo2 = oa[2][0] * t + oa[2][1] * ax + oa[2][2] * ay + oa[2][3] * ad;
-            }
-            float zbx = d1 * gx + 2.f * d2 * zx * gd;
-            float zby = d1 * gy + 2.f * d2 * zy * gd;
-            float zbd = d1 * gd;
-            zb = d1 * ga + d2 * (zx * gx + zy * gy) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd;
-            z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
-            dbv = zb;
-            dwx = zb * px[0] + zbx;
-            dwy = zb * py[0] + zby;
-          } else {
-            float zq[4];
-            dbv = 0.f; dwx = 0.f; dwy = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float t = (j == 0 ? s0[e] : j == 1 ? s1[e] : j == 2 ? s2[e] : s3[e]);
-              if (l == L - 1) { wo0 += oa[0][j] * t; wo1 += oa[1][j] * t; wo2 += oa[2][j] * t; }
-              zq[j] = (1.f - t * t) * acc[j][r];
-              dbv += zq[j]; dwx += zq[j] * px[j]; dwy += zq[j] * py[j];
-            }
-            z0[e] = zq[0]; z1[e] = zq[1]; z2[e] = zq[2]; z3[e] = zq[3];
+          if (l == L - 1) {   // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
+            float ax = d1 * zx, ay = d1 * zy, ad = d2 * (zx * zx + zy * zy) + d1 * zd;
+            wo0 = oa[0][0] * t + oa[0][1] * ax + oa[0][2] * ay + oa[0][3] * ad;
+            wo1 = oa[1][0] * t + oa[1][1] * ax + oa[1][2] * ay + oa[1][3] * ad;
+            wo2 = oa[2][0] * t + oa[2][1] * ax + oa[2][2] * ay + oa[2][3] * ad;
           }
-          // skinny gradients: sum over the 32 columns held by this half-wave
-          dbv = red32(dbv);
-          if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
+          float zbx = d1 * gx[e] + 2.f * d2 * zx * gd[e];
+          float zby = d1 * gy[e] + 2.f * d2 * zy * gd[e];
+          float zbd = d1 * gd[e];
+          float zb = d1 * ga[e] + d2 * (zx * gx[e] + zy * gy[e]) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd[e];
+          z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
+          float dbv = red_cols<PPL>(zb);
+          if (pp == 0) sgacc[sg_db(HP, l) + o] += dbv;
           if (l == L - 1) {
-            wo0 = red32(wo0); wo1 = red32(wo1); wo2 = red32(wo2);
-            if (col == 0) {
+            wo0 = red_cols<PPL>(wo0); wo1 = red_cols<PPL>(wo1); wo2 = red_cols<PPL>(wo2);
+            if (pp == 0) {
               sgacc[sg_wout(HP, L) + o] += wo0;
               sgacc[sg_wout(HP, L) + HP + o] += wo1;
               sgacc[sg_wout(HP, L) + 2 * HP + o] += wo2;
             }
           }
           if (l == 0) {
-            dwx = red32(dwx); dwy = red32(dwy);
-            if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
+            float dwx = red_cols<PPL>(zb * px[0] + zbx), dwy = red_cols<PPL>(zb * py[0] + zby);
+            if (pp == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
           }
         }
         if (l > 0) {
-          const int off = XI::chunk_off(col, (ob >> 3) + g) + 8 * h;
-          u32x2 hi, lo;
-          split4(z0[0], z0[1], z0[2], z0[3], hi, lo);
-          *reinterpret_cast<u32x2*>(Xb + 0 * XI::PLANE * 2 + off) = hi;
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 0 * XI::PLANE * 2 + off) = lo;
-          split4(z1[0], z1[1], z1[2], z1[3], hi, lo);
-          *reinterpret_cast<u32x2*>(Xb + 1 * XI::PLANE * 2 + off) = hi;
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 1 * XI::PLANE * 2 + off) = lo;
-          split4(z2[0], z2[1], z2[2], z2[3], hi, lo);
-          *reinterpret_cast<u32x2*>(Xb + 2 * XI::PLANE * 2 + off) = hi;
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 2 * XI::PLANE * 2 + off) = lo;
-          split4(z3[0], z3[1], z3[2], z3[3], hi, lo);
-          *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = hi;
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = lo;
-          f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-          Zg[0 * (HP / 4) * 32] = z0; Zg[1 * (HP / 4) * 32] = z1;
-          Zg[2 * (HP / 4) * 32] = z2; Zg[3 * (HP / 4) * 32] = z3;
+          const int off = XI::chunk_off(pp, (ob >> 3) + g) + 8 * h;
+          u32x2 vh, vl;
+          split4(z0[0], z0[1], z0[2], z0[3], vh, vl);
+          *reinterpret_cast<u32x2*>(Xb + 0 * XI::PLANE * 2 + off) = vh;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 0 * XI::PLANE * 2 + off) = vl;
+          split4(z1[0], z1[1], z1[2], z1[3], vh, vl);
+          *reinterpret_cast<u32x2*>(Xb + 1 * XI::PLANE * 2 + off) = vh;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 1 * XI::PLANE * 2 + off) = vl;
+          split4(z2[0], z2[1], z2[2], z2[3], vh, vl);
+          *reinterpret_cast<u32x2*>(Xb + 2 * XI::PLANE * 2 + off) = vh;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 2 * XI::PLANE * 2 + off) = vl;
+          split4(z3[0], z3[1], z3[2], z3[3], vh, vl);
+          *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
+          f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
+          Zg[0 * (HP / 4) * PPL] = z0; Zg[1 * (HP / 4) * PPL] = z1;
+          Zg[2 * (HP / 4) * PPL] = z2; Zg[3 * (HP / 4) * PPL] = z3;
+        }
+      };
+
+      if (NS == 4 && COLS == 128) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 ga, gx, gy, gd;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ga[e] = acc[0][4 * g + e]; gx[e] = acc[1][4 * g + e];
+            gy[e] = acc[2 % NTL][4 * g + e]; gd[e] = acc[3 % NTL][4 * g + e];
+          }
+          adj_quad(g, ga, gx, gy, gd);
+        }
+      } else if (NS == 4) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[0][q]), __float_as_uint(acc[0][q + 8]), false, false);
+          auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[1 % NTL][q]), __float_as_uint(acc[1 % NTL][q + 8]), false, false);
+          acc[0][q] = __uint_as_float(s01[0]); acc[0][q + 8] = __uint_as_float(s01[1]);
+          acc[1 % NTL][q] = __uint_as_float(s23[0]); acc[1 % NTL][q + 8] = __uint_as_float(s23[1]);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+          f32x4 ga, gx, gy, gd;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int q = 4 * gq + e;
+            ga[e] = acc[0][q]; gx[e] = acc[0][q + 8]; gy[e] = acc[1 % NTL][q]; gd[e] = acc[1 % NTL][q + 8];
+          }
+          adj_quad(gq + 2 * hi, ga, gx, gy, gd);
+        }
+      } else {
+        // value mode: z-bar = (1 - t^2) * g per column; every accumulator tile is 1 or 2 planes
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 zj[NTL];
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) {
+            const int plane = COLS == 128 ? j : 2 * j + hi;
+            const f32x4 t4 = *(reinterpret_cast<const f32x4*>(Sl) + ((size_t)plane * (HP / 4) + (ob >> 2) + 2 * g + h) * PPL + pp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zj[j][e] = (1.f - t4[e] * t4[e]) * acc[j][4 * g + e];
+            if (l == L - 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int o = ob + 8 * g + 4 * h + e;
+                float w0 = red_cols<32>(oc[0][j] * t4[e]), w1 = red_cols<32>(oc[1][j] * t4[e]), w2 = red_cols<32>(oc[2][j] * t4[e]);
+                if (col == 0) {
+                  sgacc[sg_wout(HP, L) + o] += w0;
+                  sgacc[sg_wout(HP, L) + HP + o] += w1;
+                  sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+                }
+              }
+            }
+            if (l > 0) {
+              const int off = XI::chunk_off(pp, (ob >> 3) + g) + 8 * h;
+              u32x2 vh, vl;
+              split4(zj[j][0], zj[j][1], zj[j][2], zj[j][3], vh, vl);
+              *reinterpret_cast<u32x2*>(Xb + plane * XI::PLANE * 2 + off) = vh;
+              if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + plane * XI::PLANE * 2 + off) = vl;
+              *(reinterpret_cast<f32x4*>(Zl) + ((size_t)plane * (HP / 4) + (ob >> 2) + 2 * g + h) * PPL + pp) = zj[j];
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int o = ob + 8 * g + 4 * h + e;
+            float dbv = 0.f, dwx = 0.f, dwy = 0.f;
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) { dbv += zj[j][e]; dwx += zj[j][e] * px[j]; dwy += zj[j][e] * py[j]; }
+            dbv = red_cols<32>(dbv);
+            if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
+            if (l == 0) {
+              dwx = red_cols<32>(dwx); dwy = red_cols<32>(dwy);
+              if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
+            }
+          }
         }
       }
       if (l == 0) break;
@@ -206,16 +275,18 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
       // ------------- G_{l-1}[i][col] = sum_o W_l[o][i] Zb_l[o][col]  (bf16 MFMA) -------------
       {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NTL; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        u32x4 bh[4], bo[4];
+        const unsigned char* Xl = Xb + (COLS == 128 ? 0 : hi * XI::PLANE * 2);
+        constexpr int TSTR = (COLS == 128 ? 1 : 2) * XI::PLANE * 2;
+        u32x4 bh[NTL], bo[NTL];
         {
-          const int off0 = XI::chunk_off(col, h);
+          const int off0 = XI::chunk_off(pp, h);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            bh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off0);
-            if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off0);
+          for (int j = 0; j < NTL; ++j) {
+            bh[j] = *reinterpret_cast<const u32x4*>(Xl + j * TSTR + off0);
+            if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off0);
           }
         }
 #pragma unroll
@@ -224,17 +295,17 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
             wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
             if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
           }
-          u32x4 nh[4], no[4];
+          u32x4 nh[NTL], no[NTL];
           if (s + 1 < KS) {
-            const int off = XI::chunk_off(col, 2 * (s + 1) + h);
+            const int off = XI::chunk_off(pp, 2 * (s + 1) + h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              nh[j] = *reinterpret_cast<const u32x4*>(Xb + j * XI::PLANE * 2 + off);
-              if (TERMS == 3) no[j] = *reinterpret_cast<const u32x4*>(Xb + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+            for (int j = 0; j < NTL; ++j) {
+              nh[j] = *reinterpret_cast<const u32x4*>(Xl + j * TSTR + off);
+              if (TERMS == 3) no[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off);
             }
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < NTL; ++j) {
             if (TERMS == 3) {
               acc[j] = mfma_bf16(wh[s % RING], bo[j], acc[j]);
               acc[j] = mfma_bf16(wl[s % RING], bh[j], acc[j]);
@@ -243,7 +314,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
           }
           if (s + 1 < KS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bh[j] = nh[j]; if (TERMS == 3) bo[j] = no[j]; }
+            for (int j = 0; j < NTL; ++j) { bh[j] = nh[j]; if (TERMS == 3) bo[j] = no[j]; }
           }
         }
       }
@@ -252,7 +323,6 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
     __syncthreads();
   }
   // ---------------- flush ----------------
-  // output-bias gradient: per-thread partials -> fixed-order sum
   float* red = reinterpret_cast<float*>(ldsb);
   __syncthreads();
 #pragma unroll
@@ -268,41 +338,53 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
   for (int i = tid; i < SG; i += NT) out[i] = sgacc[i];
 }
 
-template <int HP>
-static size_t lds_bytes_t(int L) { return XImg<HP>::BYTES + ((size_t)4 * 128 + sg_total(HP, L)) * sizeof(float); }
+template <int HP, int COLS>
+static size_t lds_bytes_t(int L) { return XImg<HP, COLS / 4>::BYTES + ((size_t)4 * COLS + sg_total(HP, L)) * sizeof(float); }
 
-size_t bwd_bf16_lds_bytes(int HP, int L) {
-  switch (HP) {
-    case 32: return lds_bytes_t<32>(L); case 64: return lds_bytes_t<64>(L); case 96: return lds_bytes_t<96>(L);
-    case 128: return lds_bytes_t<128>(L); case 160: return lds_bytes_t<160>(L); case 192: return lds_bytes_t<192>(L);
-    case 224: return lds_bytes_t<224>(L); default: return lds_bytes_t<256>(L);
-  }
+size_t bwd_bf16_lds_bytes(int HP, int L, int cols) {
+#define LB(hp) case hp: return cols == 64 ? lds_bytes_t<hp, 64>(L) : lds_bytes_t<hp, 128>(L);
+  switch (HP) { LB(32) LB(64) LB(96) LB(128) LB(160) LB(192) LB(224) default: return cols == 64 ? lds_bytes_t<256, 64>(L) : lds_bytes_t<256, 128>(L); }
+#undef LB
 }
 
-template <int HP, int NS, int TERMS>
+template <int HP, int NS, int TERMS, int COLS>
 static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
-  size_t lds = lds_bytes_t<HP>(a.L);
+  size_t lds = lds_bytes_t<HP, COLS>(a.L);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_bf16_kernel<HP, NS, TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_bf16_kernel<HP, NS, TERMS, COLS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((bwd_bf16_kernel<HP, NS, TERMS>), dim3(grid), dim3(HP * 2), lds, s, a);
+  hipLaunchKernelGGL((bwd_bf16_kernel<HP, NS, TERMS, COLS>), dim3(grid), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-#define BWD_CASE(hp)                                                                         \
-  case hp:                                                                                   \
-    if (terms == 3) return NS == 4 ? launch_one<hp, 4, 3>(a, grid, s) : launch_one<hp, 1, 3>(a, grid, s); \
-    return NS == 4 ? launch_one<hp, 4, 1>(a, grid, s) : launch_one<hp, 1, 1>(a, grid, s);
+template <int HP, int COLS>
+static int launch_hp(int NS, int terms, const BwdArgs& a, int grid, hipStream_t s) {
+  if (terms == 3) return NS == 4 ? launch_one<HP, 4, 3, COLS>(a, grid, s) : launch_one<HP, 1, 3, COLS>(a, grid, s);
+  return NS == 4 ? launch_one<HP, 4, 1, COLS>(a, grid, s) : launch_one<HP, 1, 1, COLS>(a, grid, s);
+}
 
-int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s) {
+int launch_bwd_bf16(int HP, int NS, int terms, int cols, const BwdArgs& a, int grid, hipStream_t s) {
+  if (cols == 64) {
+    switch (HP) {
+      case 128: return launch_hp<128, 64>(NS, terms, a, grid, s);
+      case 256: return launch_hp<256, 64>(NS, terms, a, grid, s);
+      default: return -1000;
+    }
+  }
   switch (HP) {
-    BWD_CASE(32) BWD_CASE(64) BWD_CASE(96) BWD_CASE(128)
-    BWD_CASE(160) BWD_CASE(192) BWD_CASE(224) BWD_CASE(256)
+    case 32: return launch_hp<32, 128>(NS, terms, a, grid, s);
+    case 64: return launch_hp<64, 128>(NS, terms, a, grid, s);
+    case 96: return launch_hp<96, 128>(NS, terms, a, grid, s);
+    case 128: return launch_hp<128, 128>(NS, terms, a, grid, s);
+    case 160: return launch_hp<160, 128>(NS, terms, a, grid, s);
+    case 192: return launch_hp<192, 128>(NS, terms, a, grid, s);
+    case 224: return launch_hp<224, 128>(NS, terms, a, grid, s);
+    case 256: return launch_hp<256, 128>(NS, terms, a, grid, s);
     default: return -1000;
   }
 }

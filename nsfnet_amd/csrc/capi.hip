@@ -33,8 +33,14 @@ static int terms_of(int prec) { return prec == 1 ? 3 : 1; }
 static int env_int(const char* name, int dflt);
 static int pick_wide(const pinn_net_s* n) {
   if (n->HP > 256) return 1;
+  if (n->HP != 256 && n->HP != 128) return 0;
   const bool fp32 = !n->prec_fwd && !n->prec_bwd && !n->prec_dw;
-  return fp32 && n->HP == 256 && env_int("PINN_FORCE_WIDE", 1) != 0;
+  // measured (6x256, 360k pts): fp32 26.2 vs 29.6 ms/step in favour of 64-column tiles; bf16x3 13.4 vs 12.6 ms
+  // against them.  PINN_TILE_COLS=64|128 overrides the choice (HP 128/256 only).
+  const int force = env_int("PINN_TILE_COLS", 0);
+  if (force == 64) return 1;
+  if (force == 128) return 0;
+  return fp32 && n->HP == 256;
 }
 
 struct pinn_plan_s {
@@ -124,9 +130,10 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     if (b > bw) b = bw;
     return b < 1 ? 1 : b;
   };
-  const size_t lds_f = wide ? fwd_wide_lds_bytes(HP) : net->prec_fwd ? fwd_bf16_lds_bytes(HP, L) : fwd_lds_bytes(HP);
-  const size_t lds_b = wide ? bwd_wide_lds_bytes(HP, L) : net->prec_bwd ? bwd_bf16_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
-  const size_t lds_d = wide ? dw_wide_lds_bytes() : net->prec_dw ? dw_bf16_lds_bytes(HP) : dw_lds_bytes(HP);
+  const int cols = wide ? 64 : 128;
+  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP, L, cols) : wide ? fwd_wide_lds_bytes(HP) : fwd_lds_bytes(HP);
+  const size_t lds_b = net->prec_bwd ? bwd_bf16_lds_bytes(HP, L, cols) : wide ? bwd_wide_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
+  const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : wide ? dw_wide_lds_bytes() : dw_lds_bytes(HP);
   if (lds_b > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
@@ -178,9 +185,10 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 1) : 0;
-  int rc = plan->net.wide ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
-           : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                                : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
+  const int cols = plan->net.wide ? 64 : 128;
+  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream)
+           : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
+                              : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -194,9 +202,10 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
+  if (plan->net.prec_dw)
+    return launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), plan->net.wide ? 64 : 128, d, s);
   if (plan->net.wide) return launch_dw_wide(plan->net.HP, plan->streams, d, s);
-  return plan->net.prec_dw ? launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s)
-                           : launch_dw(plan->net.HP, plan->streams, d, s);
+  return launch_dw(plan->net.HP, plan->streams, d, s);
 }
 
 int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
@@ -215,9 +224,10 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {
-    rc = plan->net.wide ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
-         : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                              : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+    const int cols = plan->net.wide ? 64 : 128;
+    rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream)
+         : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
+                            : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
   }
   if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
@@ -250,9 +260,10 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = save ? WS(plan, off_oadj) : nullptr;
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
-  int rc = plan->net.wide ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
-           : plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                                : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
+  const int cols = plan->net.wide ? 64 : 128;
+  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream)
+           : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
+                              : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -272,9 +283,10 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
-  int rc = plan->net.wide ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
-           : plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                                : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
+  const int cols = plan->net.wide ? 64 : 128;
+  int rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream)
+           : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
+                              : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");
   rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;

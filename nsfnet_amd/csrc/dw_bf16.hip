@@ -34,8 +34,11 @@ __device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
   return __builtin_bit_cast(u32x2, v);
 }
 
-template <int HP, int NS, int TERMS>
+// PPL = points per plane of a tile: 32 (128-column tiles) or 16 (64-column tiles)
+template <int HP, int NS, int TERMS, int PPL>
 __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
+  constexpr int CPT = PPL / 8;                 // 32-column chunks per tile
+  constexpr size_t ABLK = (size_t)HP * 4 * PPL; // floats per (tile, layer) activation block
   using DI = DwImg<HP>;
   constexpr int T = HP / 32;
   constexpr int TM = DwCfgB<T>::TM, TN = DwCfgB<T>::TN;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
   const int l = blockIdx.y + 1;
   const int g = blockIdx.x;
   const int t0 = (int)((long)g * a.ntiles / a.groups), t1 = (int)((long)(g + 1) * a.ntiles / a.groups);
-  const int nch = (t1 - t0) * 4;
+  const int nch = (t1 - t0) * CPT;
   const int p = tid & 7, og = tid >> 3;
 
   f32x16 acc[TM][TN];
@@ -60,13 +63,13 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
 
   f32x4 zr[4], sr[4];
   auto gload = [&](int ch) {
-    const int tile = t0 + (ch >> 2), c = ch & 3;
-    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
-    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
+    const int tile = t0 + ch / CPT, c = ch % CPT;
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + (size_t)og * PPL + 8 * c + p;
+    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + (size_t)og * PPL + 8 * c + p;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = Zg[(size_t)s * (HP / 4) * 32];
-      sr[s] = Sg[(size_t)s * (HP / 4) * 32];
+      zr[s] = Zg[(size_t)s * (HP / 4) * PPL];
+      sr[s] = Sg[(size_t)s * (HP / 4) * PPL];
     }
   };
   auto lstore = [&](int buf) {
@@ -168,31 +171,45 @@ size_t dw_bf16_lds_bytes(int HP) {
   }
 }
 
-template <int HP, int NS, int TERMS>
+template <int HP, int NS, int TERMS, int PPL>
 static int launch_one(const DwArgs& a, hipStream_t s) {
   size_t lds = lds_bytes_t<HP>();
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS, PPL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return -(int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
+  hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS, PPL>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-#define DW_CASE(hp)                                                                   \
-  case hp:                                                                            \
-    if (terms == 3) return NS == 4 ? launch_one<hp, 4, 3>(a, s) : launch_one<hp, 1, 3>(a, s); \
-    return NS == 4 ? launch_one<hp, 4, 1>(a, s) : launch_one<hp, 1, 1>(a, s);
+template <int HP, int PPL>
+static int launch_hp(int NS, int terms, const DwArgs& a, hipStream_t s) {
+  if (terms == 3) return NS == 4 ? launch_one<HP, 4, 3, PPL>(a, s) : launch_one<HP, 1, 3, PPL>(a, s);
+  return NS == 4 ? launch_one<HP, 4, 1, PPL>(a, s) : launch_one<HP, 1, 1, PPL>(a, s);
+}
 
-int launch_dw_bf16(int HP, int NS, int terms, const DwArgs& a, hipStream_t s) {
+int launch_dw_bf16(int HP, int NS, int terms, int cols, const DwArgs& a, hipStream_t s) {
   if (a.L <= 1 || a.groups <= 0) return 0;
+  if (cols == 64) {
+    switch (HP) {
+      case 128: return launch_hp<128, 16>(NS, terms, a, s);
+      case 256: return launch_hp<256, 16>(NS, terms, a, s);
+      default: return -1000;
+    }
+  }
   switch (HP) {
-    DW_CASE(32) DW_CASE(64) DW_CASE(96) DW_CASE(128)
-    DW_CASE(160) DW_CASE(192) DW_CASE(224) DW_CASE(256)
+    case 32: return launch_hp<32, 32>(NS, terms, a, s);
+    case 64: return launch_hp<64, 32>(NS, terms, a, s);
+    case 96: return launch_hp<96, 32>(NS, terms, a, s);
+    case 128: return launch_hp<128, 32>(NS, terms, a, s);
+    case 160: return launch_hp<160, 32>(NS, terms, a, s);
+    case 192: return launch_hp<192, 32>(NS, terms, a, s);
+    case 224: return launch_hp<224, 32>(NS, terms, a, s);
+    case 256: return launch_hp<256, 32>(NS, terms, a, s);
     default: return -1000;
   }
 }

@@ -82,11 +82,12 @@ size_t fwd_wide_lds_bytes(int HP);
 size_t bwd_wide_lds_bytes(int HP, int L);
 size_t dw_wide_lds_bytes();
 // bf16 MFMA variants (terms = 3: bf16x3 split, terms = 1: plain bf16)
-int launch_fwd_bf16(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
-int launch_bwd_bf16(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);
-int launch_dw_bf16(int HP, int NS, int terms, const DwArgs& a, hipStream_t s);
-size_t fwd_bf16_lds_bytes(int HP, int L);
-size_t bwd_bf16_lds_bytes(int HP, int L);
+// cols = 128 (32-point tiles) or 64 (16-point tiles, HP 128/256 only)
+int launch_fwd_bf16(int HP, int NS, int terms, int cols, const FwdArgs& a, int grid, hipStream_t s);
+int launch_bwd_bf16(int HP, int NS, int terms, int cols, const BwdArgs& a, int grid, hipStream_t s);
+int launch_dw_bf16(int HP, int NS, int terms, int cols, const DwArgs& a, hipStream_t s);
+size_t fwd_bf16_lds_bytes(int HP, int L, int cols);
+size_t bwd_bf16_lds_bytes(int HP, int L, int cols);
 size_t dw_bf16_lds_bytes(int HP);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);

@@ -226,3 +226,28 @@ def test_config5_shape_ev_8x400_with_4x40_entropy_net():
     assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
     ge = fr.backward1(Pe, x.astype(np.float64), y.astype(np.float64), saved_e, r["e_adj"].reshape(-1, 1))
     assert _rel_l2(E.grads_e.cpu().numpy(), ge) < 1e-4
+
+
+@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_64_column_tile_kernels_at_narrow_widths(H, prec, monkeypatch):
+    """The 16-point-tile kernels (default only for fp32 at hidden = 256 and for wide nets) forced on
+    for both precisions at hidden 128 / 256 through PINN_TILE_COLS."""
+    monkeypatch.setenv("PINN_TILE_COLS", "64")
+    eng = _engine_mod()
+    L, N, Nb, Re = 3, 200, 50, 400.0
+    flat = _rand_params(3, L, H, seed=3 + H)
+    rng = np.random.RandomState(H)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::40][:Nb].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(torch.device("cuda:0"), L, H, Re, alpha_b=10.0, alpha_e=1.0, precision=prec)
+    E.net.set_flat(torch.tensor(flat)); E.set_collocation(x, y); E.set_boundary(xb, yb, ub, vb)
+    assert E.plan_f.npad == ((N + 15) // 16) * 16          # 16-point tiles are in use
+    E.loss_and_grad()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re)
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    tol = 2e-5 if prec == "fp32" else 5e-4
+    for k, name in enumerate(("eq1", "eq2", "eq3")):
+        assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < tol, name
+    assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
