@@ -46,7 +46,12 @@ def test_host_only_entry_points(lib):
     assert lib.pinn_plan_workspace_bytes(p, 1) > lib.pinn_plan_workspace_bytes(p, 0) > 0
     q = ctypes.c_void_p()
     assert lib.pinn_plan_create(h, 2052, 1, ctypes.byref(q)) == 0
-    assert lib.pinn_plan_padded_points(q) == 2176          # 17 tiles of 128
+    assert lib.pinn_plan_padded_points(q) == 2112          # fp32 @ hidden 256: 33 tiles of 64 points
+    assert lib.pinn_net_set_precision(h, 1, 1, 1) == 0     # bf16x3: 128-column tiles
+    q2 = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 2052, 1, ctypes.byref(q2)) == 0
+    assert lib.pinn_plan_padded_points(q2) == 2176         # 17 tiles of 128 points
+    lib.pinn_plan_destroy(q2)
     for handle in (p, q):
         assert lib.pinn_plan_destroy(handle) == 0
     assert lib.pinn_net_destroy(h) == 0
