@@ -8,15 +8,7 @@
 // the weight-gradient GEMM (dw.hip), and the skinny gradients (all biases, layer 0,
 // output layer) are reduced in-kernel.
 #include "kernels.h"
-
-__device__ __forceinline__ float red32(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
+#include "reduce_util.h"
 
 template <int HP, int NS>
 __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
@@ -156,10 +148,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
             z0[e] = zq[0]; z1[e] = zq[1]; z2[e] = zq[2]; z3[e] = zq[3];
           }
           // skinny gradients: sum over the 32 columns held by this half-wave
-          dbv = red32(dbv);
+          dbv = sum32(dbv);
           if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
           if (l == L - 1) {
-            wo0 = red32(wo0); wo1 = red32(wo1); wo2 = red32(wo2);
+            wo0 = sum32(wo0); wo1 = sum32(wo1); wo2 = sum32(wo2);
             if (col == 0) {
               sgacc[sg_wout(HP, L) + o] += wo0;
               sgacc[sg_wout(HP, L) + HP + o] += wo1;
@@ -167,7 +159,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
             }
           }
           if (l == 0) {
-            dwx = red32(dwx); dwy = red32(dwy);
+            dwx = sum32(dwx); dwy = sum32(dwy);
             if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
           } else {
             float* Xo = X + o * 128 + col;

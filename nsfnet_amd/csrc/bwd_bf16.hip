@@ -6,16 +6,7 @@
 // COLS = 128 / 64: tile geometry as in fwd_bf16.hip.
 #include "kernels.h"
 #include "bf16_util.h"
-
-template <int W>
-__device__ __forceinline__ float red_cols(float v) {   // sum over the W (16 or 32) lanes that share a feature
-  if (W == 32) v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
+#include "reduce_util.h"
 
 template <int HP, int NS, int TERMS, int COLS>
 __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
@@ -158,10 +149,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
           float zbd = d1 * gd[e];
           float zb = d1 * ga[e] + d2 * (zx * gx[e] + zy * gy[e]) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd[e];
           z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
-          float dbv = red_cols<PPL>(zb);
+          float dbv = sum_cols<PPL>(zb);
           if (pp == 0) sgacc[sg_db(HP, l) + o] += dbv;
           if (l == L - 1) {
-            wo0 = red_cols<PPL>(wo0); wo1 = red_cols<PPL>(wo1); wo2 = red_cols<PPL>(wo2);
+            wo0 = sum_cols<PPL>(wo0); wo1 = sum_cols<PPL>(wo1); wo2 = sum_cols<PPL>(wo2);
             if (pp == 0) {
               sgacc[sg_wout(HP, L) + o] += wo0;
               sgacc[sg_wout(HP, L) + HP + o] += wo1;
@@ -169,7 +160,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
             }
           }
           if (l == 0) {
-            float dwx = red_cols<PPL>(zb * px[0] + zbx), dwy = red_cols<PPL>(zb * py[0] + zby);
+            float dwx = sum_cols<PPL>(zb * px[0] + zbx), dwy = sum_cols<PPL>(zb * py[0] + zby);
             if (pp == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
           }
         }
@@ -238,7 +229,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const int o = ob + 8 * g + 4 * h + e;
-                float w0 = red_cols<32>(oc[0][j] * t4[e]), w1 = red_cols<32>(oc[1][j] * t4[e]), w2 = red_cols<32>(oc[2][j] * t4[e]);
+                float w0 = sum_cols<32>(oc[0][j] * t4[e]), w1 = sum_cols<32>(oc[1][j] * t4[e]), w2 = sum_cols<32>(oc[2][j] * t4[e]);
                 if (col == 0) {
                   sgacc[sg_wout(HP, L) + o] += w0;
                   sgacc[sg_wout(HP, L) + HP + o] += w1;
@@ -261,10 +252,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
             float dbv = 0.f, dwx = 0.f, dwy = 0.f;
 #pragma unroll
             for (int j = 0; j < NTL; ++j) { dbv += zj[j][e]; dwx += zj[j][e] * px[j]; dwy += zj[j][e] * py[j]; }
-            dbv = red_cols<32>(dbv);
+            dbv = sum_cols<32>(dbv);
             if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
             if (l == 0) {
-              dwx = red_cols<32>(dwx); dwy = red_cols<32>(dwy);
+              dwx = sum_cols<32>(dwx); dwy = sum_cols<32>(dwy);
               if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
             }
           }

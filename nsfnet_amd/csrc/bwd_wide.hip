@@ -3,15 +3,7 @@
 // ev-NSFnet/pinn_solver.py:469); tile geometry and the v_permlane16_swap stream exchange
 // as in fwd_wide.hip.
 #include "kernels.h"
-
-__device__ __forceinline__ float red16(float v) {
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
-}
-__device__ __forceinline__ float red32w(float v) { return red16(v + __shfl_xor(v, 16)); }
+#include "reduce_util.h"
 
 template <int HP, int NS>
 __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
@@ -153,10 +145,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
             float zbd = d1 * gd;
             float zb = d1 * ga + d2 * (zx * gx + zy * gy) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd;
             z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
-            float dbv = red16(zb);
+            float dbv = sum16(zb);
             if (pp == 0) sgacc[sg_db(HP, l) + o] += dbv;
             if (l == L - 1) {
-              wo0 = red16(wo0); wo1 = red16(wo1); wo2 = red16(wo2);
+              wo0 = sum16(wo0); wo1 = sum16(wo1); wo2 = sum16(wo2);
               if (pp == 0) {
                 sgacc[sg_wout(HP, L) + o] += wo0;
                 sgacc[sg_wout(HP, L) + HP + o] += wo1;
@@ -164,7 +156,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
               }
             }
             if (l == 0) {
-              float dwx = red16(zb * px[0] + zbx), dwy = red16(zb * py[0] + zby);
+              float dwx = sum16(zb * px[0] + zbx), dwy = sum16(zb * py[0] + zby);
               if (pp == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
             } else {
               float* Xo = X + o * COLS + pp;
@@ -196,10 +188,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
               dbv += zq; dwx += zq * px[j]; dwy += zq * py[j];
               if (l > 0) X[o * COLS + 32 * j + c] = zq;
             }
-            dbv = red32w(dbv);
+            dbv = sum32(dbv);
             if (c == 0) sgacc[sg_db(HP, l) + o] += dbv;
             if (l == L - 1) {
-              wo0 = red32w(wo0); wo1 = red32w(wo1); wo2 = red32w(wo2);
+              wo0 = sum32(wo0); wo1 = sum32(wo1); wo2 = sum32(wo2);
               if (c == 0) {
                 sgacc[sg_wout(HP, L) + o] += wo0;
                 sgacc[sg_wout(HP, L) + HP + o] += wo1;
@@ -207,7 +199,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
               }
             }
             if (l == 0) {
-              dwx = red32w(dwx); dwy = red32w(dwy);
+              dwx = sum32(dwx); dwy = sum32(dwy);
               if (c == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
             }
           }
