@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
         return o
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -22,7 +22,11 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 1) void fwd
   constexpr int PPL = COLS / 4, NTL = COLS / 32;
   using XI = XImg<HP, PPL>;
   constexpr int NW = HP / 32, NT = HP * 2, KS = HP / 16;
-  constexpr int PRE = COLS == 64 ? (KS < 2 ? KS : 2) : (KS < 4 ? KS : 4);
+#ifndef PINN_PREK
+#define PINN_PREK 4
+#endif
+  constexpr int PREK = PINN_PREK;   // weight k-steps requested ahead of the epilogue's store burst
+  constexpr int PRE = COLS == 64 ? (KS < 2 ? KS : 2) : (KS < PREK ? KS : PREK);
   constexpr int RING = (PRE + 2 < KS) ? PRE + 2 : KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* Xb = ldsb;                                   // [2][4][32][RSE] bf16
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 1) void fwd
                       const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) {
         const int off = XI::chunk_off(pp, (ob >> 3) + g) + 8 * h;
         u32x2 vh, vl;
+        if (!(a.dbg & 4)) {
         split4(a0[0], a0[1], a0[2], a0[3], vh, vl);
         *reinterpret_cast<u32x2*>(Xb + 0 * XI::PLANE * 2 + off) = vh;
         if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 0 * XI::PLANE * 2 + off) = vl;
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 1) void fwd
         split4(a3[0], a3[1], a3[2], a3[3], vh, vl);
         *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
         if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
-        if (Sl) {
+        } else { asm volatile("" :: "v"(a0[0] + a1[1] + a2[2] + a3[3])); }
+        if (Sl && !(a.dbg & 2)) {
           f32x4* Sg = reinterpret_cast<f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
           Sg[0 * (HP / 4) * PPL] = s0;
           Sg[1 * (HP / 4) * PPL] = s1;
@@ -209,9 +215,10 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 1) void fwd
             if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off0);
           }
         }
+        if (!(a.dbg & 1))
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          if (s + PRE < KS) {     // stream the weight fragments PRE k-steps ahead
+          if (s + PRE < KS && !(a.dbg & 8)) {     // stream the weight fragments PRE k-steps ahead
             wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
             if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
           }

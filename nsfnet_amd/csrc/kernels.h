@@ -33,6 +33,7 @@ struct FwdArgs {
   float coef[3];         // oadj_c = coef[c] * (pred_c - tgt_c)
   float* partials;       // [grid][PINN_NLOSS]
   int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
+  int dbg;               // timing-only ablation bits (PINN_DBG): 1 skip MFMA loop, 2 skip S stores, 4 skip LDS restage
 };
 
 struct BwdArgs {
