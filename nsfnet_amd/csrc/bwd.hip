@@ -106,8 +106,8 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-        f32x4 s0 = Sg[0 * (HP / 4) * 32], s1 = Sg[1 * (HP / 4) * 32];
-        f32x4 s2 = Sg[2 * (HP / 4) * 32], s3 = Sg[3 * (HP / 4) * 32];
+        f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * 32), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * 32);
+        f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * 32), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * 32);
         f32x4 z0, z1, z2, z3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
         }
         if (l > 0) {
           f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-          Zg[0 * (HP / 4) * 32] = z0; Zg[1 * (HP / 4) * 32] = z1;
-          Zg[2 * (HP / 4) * 32] = z2; Zg[3 * (HP / 4) * 32] = z3;
+          __builtin_nontemporal_store(z0, Zg + 0 * (HP / 4) * 32); __builtin_nontemporal_store(z1, Zg + 1 * (HP / 4) * 32);
+          __builtin_nontemporal_store(z2, Zg + 2 * (HP / 4) * 32); __builtin_nontemporal_store(z3, Zg + 3 * (HP / 4) * 32);
         }
       }
       if (l == 0) break;

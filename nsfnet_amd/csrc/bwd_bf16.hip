@@ -127,8 +127,8 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
       // residual mode: tanh adjoint of one register quad (features ob+8g+4h+e, column pp), all streams
       auto adj_quad = [&](int g, const f32x4& ga, const f32x4& gx, const f32x4& gy, const f32x4& gd) {
         const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-        f32x4 s0 = Sg[0 * (HP / 4) * PPL], s1 = Sg[1 * (HP / 4) * PPL];
-        f32x4 s2 = Sg[2 * (HP / 4) * PPL], s3 = Sg[3 * (HP / 4) * PPL];
+        f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * PPL), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * PPL);
+        f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * PPL), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * PPL);
         f32x4 z0, z1, z2, z3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -180,8 +180,8 @@ __global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
           *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
           if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
           f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-          Zg[0 * (HP / 4) * PPL] = z0; Zg[1 * (HP / 4) * PPL] = z1;
-          Zg[2 * (HP / 4) * PPL] = z2; Zg[3 * (HP / 4) * PPL] = z3;
+          __builtin_nontemporal_store(z0, Zg + 0 * (HP / 4) * PPL); __builtin_nontemporal_store(z1, Zg + 1 * (HP / 4) * PPL);
+          __builtin_nontemporal_store(z2, Zg + 2 * (HP / 4) * PPL); __builtin_nontemporal_store(z3, Zg + 3 * (HP / 4) * PPL);
         }
       };
 

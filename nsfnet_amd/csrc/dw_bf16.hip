@@ -68,8 +68,8 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + (size_t)og * PPL + 8 * c + p;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = Zg[(size_t)s * (HP / 4) * PPL];
-      sr[s] = Sg[(size_t)s * (HP / 4) * PPL];
+      zr[s] = __builtin_nontemporal_load(Zg + (size_t)s * (HP / 4) * PPL);
+      sr[s] = __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * PPL);
     }
   };
   auto lstore = [&](int buf) {

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(512) void dw_wide_kernel(DwArgs a, int HP) {
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * blk) + (size_t)oga * PPL + 8 * c + p;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = vz ? Zg[(size_t)s * (HP / 4) * PPL] : f32x4{0.f, 0.f, 0.f, 0.f};
-      sr[s] = va ? Sg[(size_t)s * (HP / 4) * PPL] : f32x4{0.f, 0.f, 0.f, 0.f};
+      zr[s] = vz ? __builtin_nontemporal_load(Zg + (size_t)s * (HP / 4) * PPL) : f32x4{0.f, 0.f, 0.f, 0.f};
+      sr[s] = va ? __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * PPL) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int buf) {

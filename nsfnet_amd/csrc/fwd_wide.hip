@@ -92,10 +92,10 @@ __global__ __launch_bounds__(HP * 2) void fwd_wide_kernel(FwdArgs a) {
           }
           if (Sl) {
             f32x4* Sg = reinterpret_cast<f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-            Sg[0 * (HP / 4) * PPL] = s0;
-            Sg[1 * (HP / 4) * PPL] = s1;
-            Sg[2 * (HP / 4) * PPL] = s2;
-            Sg[3 * (HP / 4) * PPL] = s3;
+            __builtin_nontemporal_store(s0, Sg + 0 * (HP / 4) * PPL);
+            __builtin_nontemporal_store(s1, Sg + 1 * (HP / 4) * PPL);
+            __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
+            __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
           }
         }
       } else {
