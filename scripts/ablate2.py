@@ -8,7 +8,7 @@ E.net.set_flat(bench.seeded_flat(6, 256))
 x, y = bench.grid_block(600, 600, 0, 1)
 E.set_collocation(x, y)
 f = E.plan_f
-for dbg in (0, 8, 6, 14):
+for dbg in (0, 1, 2, 4, 8, 3, 6, 7, 14):
     os.environ["PINN_DBG"] = str(dbg)
     f.forward(2000.0, save=True); torch.cuda.synchronize()
     t = bench.time_kernel(lambda: f.forward(2000.0, save=True), 5)
