@@ -33,9 +33,9 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1}
 # HBM bytes per launch of the default workload (6x256, 360k pts) from the PMC passes committed under
 # profiles/ (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None = not measured.
-PMC_TRAFFIC_BYTES = {   # profiles/r01_v2_bf16x3_pmc_summary.txt, profiles/r01_v1_fp32_pmc_summary.txt
-    ("bf16x3", "fwd_bf16_kernel"): 9.336e9, ("bf16x3", "bwd_bf16_kernel"): 1.680e10, ("bf16x3", "dw_bf16_kernel"): 1.481e10,
-    ("fp32", "fwd_kernel"): 9.363e9, ("fp32", "bwd_kernel"): 1.684e10, ("fp32", "dw_kernel"): 1.481e10,
+PMC_TRAFFIC_BYTES = {   # profiles/r01_final_bf16x3_pmc_summary.txt, profiles/r01_final_fp32_pmc_summary.txt
+    ("bf16x3", "fwd_bf16_kernel"): 8.882e9, ("bf16x3", "bwd_bf16_kernel"): 1.626e10, ("bf16x3", "dw_bf16_kernel"): 1.481e10,
+    ("fp32", "fwd_wide_kernel"): 8.885e9, ("fp32", "bwd_wide_kernel"): 1.627e10, ("fp32", "dw_wide_kernel"): 1.481e10,
 }
 
 
@@ -207,7 +207,8 @@ def main():
         log("[%s] kernel ms: fwd %.3f bwd %.3f dw %.3f" % (prec, t_fwd, t_bwd, t_dw))
         pw = weight_count(L, H)
         flops_each = 8.0 * pw * n_local        # fwd, dX sweep and dW GEMM each carry 2*4*P_w FLOP per point
-        names = {"fp32": ("fwd_kernel", "bwd_kernel", "dw_kernel"),
+        wide = H > 256 or (H > 224 and prec == "fp32")      # 64-column-tile kernels (csrc/capi.hip pick_wide)
+        names = {"fp32": ("fwd_wide_kernel", "bwd_wide_kernel", "dw_wide_kernel") if wide else ("fwd_kernel", "bwd_kernel", "dw_kernel"),
                  "bf16x3": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel"),
                  "bf16": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel")}[prec]
         kernels = dict(zip(names, (t_fwd, t_bwd, t_dw)))
@@ -219,7 +220,8 @@ def main():
                     traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[prec],
                     mfma_issue_frac=achieved * MFMA_PER_PRODUCT[prec] / peak,
                     kernel_ms={k: round(v, 4) for k, v in kernels.items()},
-                    step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12)
+                    step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12,
+                    forward_only_evals_per_s=n_local / (t_fwd * 1e-3))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
