@@ -25,17 +25,21 @@ class DataLoader:
         self.coord_scale = 2.0 if coord_transform else 1.0
 
     def loading_boundary_data(self):
-        """4 x 513 wall points; regularised lid u = 1 - cosh(10(x-.5))/cosh(5), v = 0
-        (cavity_data.py:38-76)."""
-        Nx = Ny = 513
-        r_const = 10
-        sx = np.linspace(self.x_min, self.x_max, num=Nx)
-        sy = np.linspace(self.y_min, self.y_max, num=Ny)
-        u_upper = 1 - np.cosh(r_const * (sx - 0.5)) / np.cosh(r_const * 0.5)
-        x_b = np.concatenate([sx, sx, self.x_min * np.ones([Ny]), self.x_max * np.ones([Ny])]).reshape([-1, 1])
-        y_b = np.concatenate([self.y_min * np.ones([Nx]), self.y_max * np.ones([Nx]), sy, sy]).reshape([-1, 1])
-        u_b = np.concatenate([np.zeros([Nx]), u_upper, np.zeros([Ny]), np.zeros([Ny])]).reshape([-1, 1])
-        v_b = np.zeros([x_b.shape[0]]).reshape([-1, 1])
+        """4 x 513 wall points in the order bottom, top (lid), left, right; regularised lid
+        u = 1 - cosh(10 (x - 0.5)) / cosh(5), v = 0 everywhere (cavity_data.py:38-76)."""
+        n_side, sharpness = 513, 10
+        along_x = np.linspace(self.x_min, self.x_max, num=n_side)
+        along_y = np.linspace(self.y_min, self.y_max, num=n_side)
+        lid = 1 - np.cosh(sharpness * (along_x - 0.5)) / np.cosh(sharpness * 0.5)
+        zeros = np.zeros([n_side])
+        walls = [  # (x, y, u) per wall
+            (along_x, self.y_min * np.ones([n_side]), zeros),
+            (along_x, self.y_max * np.ones([n_side]), lid),
+            (self.x_min * np.ones([n_side]), along_y, zeros),
+            (self.x_max * np.ones([n_side]), along_y, zeros),
+        ]
+        x_b, y_b, u_b = (np.concatenate([wall[k] for wall in walls], axis=0).reshape([-1, 1]) for k in range(3))
+        v_b = np.zeros_like(x_b)
         pts = np.hstack((x_b, y_b))
         if self.coord_transform:
             pts = self._to_centered_coords(pts)
@@ -44,10 +48,8 @@ class DataLoader:
         self.pts_bc = pts
         if self.sdf_enabled:
             self._bc_tree = cKDTree(self.pts_bc)
-        print('-----------------------------')
-        print('N_train_bcs: ' + str(x_b.shape[0]))
-        print('N_train_equ: ' + str(self.N_f))
-        print('-----------------------------')
+        for line in ('-' * 29, 'N_train_bcs: %d' % x_b.shape[0], 'N_train_equ: %d' % self.N_f, '-' * 29):
+            print(line)
         return x_b, y_b, u_b, v_b
 
     def loading_training_data(self):
@@ -68,19 +70,17 @@ class DataLoader:
         return xye[:, 0:1], xye[:, 1:2]
 
     def _compute_sdf_weights(self, pts):
-        """w = min_w + (1 - min_w) exp(-decay d), normalised to mean 1 (ev :118-130)."""
+        """w = min_w + (1 - min_w) exp(-decay d), d = distance to the nearest wall point, normalised to
+        mean 1 and kept as float32 (ev :118-130)."""
         if self._bc_tree is None:
             self._bc_tree = cKDTree(self.pts_bc)
-        dists, _ = self._bc_tree.query(pts)
-        min_w = float(getattr(self.sdf_config, 'min_weight', 0.2)) if self.sdf_config else 0.2
-        decay = float(getattr(self.sdf_config, 'decay', 5.0)) if self.sdf_config else 5.0
-        min_w = max(1e-6, min(min_w, 1.0))
-        decay = max(0.0, decay)
-        weights = min_w + (1.0 - min_w) * np.exp(-decay * dists)
-        mean_w = np.mean(weights)
-        if mean_w > 0:
-            weights = weights / mean_w
-        self.sdf_weights = weights.astype(np.float32)
+        cfg = self.sdf_config
+        floor = min(max(float(getattr(cfg, 'min_weight', 0.2)) if cfg else 0.2, 1e-6), 1.0)
+        rate = max(float(getattr(cfg, 'decay', 5.0)) if cfg else 5.0, 0.0)
+        wall_dist = self._bc_tree.query(pts)[0]
+        w = floor + (1.0 - floor) * np.exp(-rate * wall_dist)
+        mean = np.mean(w)
+        self.sdf_weights = (w / mean if mean > 0 else w).astype(np.float32)
 
     def get_sdf_weights(self):
         return self.sdf_weights

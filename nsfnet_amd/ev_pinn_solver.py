@@ -361,13 +361,9 @@ class PysicsInformedNeuralNetwork:
         def fmt_t(sec):
             if sec == float('inf'):
                 return 'INF'
-            if sec < 60:
-                return f"{sec:.1f}s"
-            m, s = divmod(sec, 60)
-            if m < 60:
-                return f"{int(m)}m{s:04.1f}s"
-            h, m = divmod(m, 60)
-            return f"{int(h)}h{int(m)}m"
+            h, rem = divmod(sec, 3600.0)
+            m, s_ = divmod(rem, 60.0)
+            return ("%dh%dm" % (h, m)) if h >= 1 else (("%dm%04.1fs" % (m, s_)) if m >= 1 else ("%.1fs" % s_))
 
         try:
             mem_alloc = torch.cuda.memory_allocated(self.device) / 1024**2

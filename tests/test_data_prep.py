@@ -12,7 +12,10 @@ from nsfnet_amd import cavity_data, tools
 def test_lhs_sort_and_sdf_match_reference(golden_dir, capsys):
     g = np.load(os.path.join(golden_dir, "data_prep.npz"))
     dl = cavity_data.DataLoader(N_f=600)
-    dl.loading_boundary_data()
+    bc = dl.loading_boundary_data()
+    ref_bc = np.load(os.path.join(golden_dir, "nsfnet_4x50_re100.npz"))
+    for mine, key in zip(bc, ("x_b", "y_b", "u_b", "v_b")):
+        np.testing.assert_array_equal(mine, ref_bc[key])       # reference DataLoader's boundary set, bit for bit
     np.random.seed(123)
     x, y = dl.loading_training_data()
     np.testing.assert_array_equal(x, g["x_sorted"])
