@@ -126,6 +126,12 @@ int pinn_grad_reduce(pinn_net_t net, int nsrc, const pinn_plan_t* plans, void* c
 int pinn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* Same update with the step count in DEVICE memory (*step_counter = steps taken so far; the call uses
+ * t = *step_counter + 1 for the bias corrections and then increments it), so that a whole training step can be
+ * captured in a hipGraph and replayed without host-side scalars changing between steps. */
+int pinn_adam_step_dev(float* params, const float* grads, float* m, float* v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int64_t* step_counter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

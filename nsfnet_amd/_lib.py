@@ -39,6 +39,8 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p]),
     "pinn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                c_float, c_float, c_float, c_float, c_int64, c_void_p]),
+    "pinn_adam_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                   c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -325,4 +325,12 @@ int pinn_adam_step(float* params, const float* grads, float* m, float* v, int64_
   return rc ? hipfail(rc, "pinn_adam_step") : 0;
 }
 
+int pinn_adam_step_dev(float* params, const float* grads, float* m, float* v, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int64_t* step_counter, void* stream) {
+  if (!params || !grads || !m || !v || !step_counter) return fail(-22, "pinn_adam_step_dev: null argument%s");
+  int rc = launch_adam_dev(params, grads, m, v, (long)n, lr, beta1, beta2, eps,
+                           reinterpret_cast<long long*>(step_counter), (hipStream_t)stream);
+  return rc ? hipfail(rc, "pinn_adam_step_dev") : 0;
+}
+
 }  // extern "C"

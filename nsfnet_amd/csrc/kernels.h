@@ -92,5 +92,7 @@ size_t bwd_bf16_lds_bytes(int HP, int L, int cols);
 size_t dw_bf16_lds_bytes(int HP);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                    float eps, long long* step_counter, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float step_size, float b1, float b2,
                 float eps, float bc2_sqrt, hipStream_t s);

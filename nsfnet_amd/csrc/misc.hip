@@ -168,6 +168,36 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Same update with the step count kept ON THE DEVICE (bias corrections computed in-kernel), so the whole
+// training step can be captured once in a hipGraph and replayed: no host scalar changes between steps.
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                const long long* __restrict__ step_counter) {
+  const double t = (double)(*step_counter + 1);
+  const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    float mi = m[i] + (gi - m[i]) * (1.f - b1);
+    float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+__global__ void counter_inc_kernel(long long* c) { *c += 1; }
+
+int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                    float eps, long long* step_counter, hipStream_t s) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, step_counter);
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, step_counter);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 int launch_adam(float* p, const float* g, float* m, float* v, long n, float step_size, float b1, float b2,
                 float eps, float bc2_sqrt, hipStream_t s) {
   if (n <= 0) return 0;

@@ -74,7 +74,8 @@ class DeviceNet:
         self.prep = torch.zeros(int(self.lib.pinn_net_prep_floats(h)), dtype=torch.float32, device=device)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
-        self.adam_t = 0
+        self.adam_t = 0                                                   # steps taken (host mirror)
+        self.adam_t_dev = torch.zeros(1, dtype=torch.int64, device=device)   # the counter the kernel uses
 
     def __del__(self):
         try:
@@ -123,12 +124,15 @@ class DeviceNet:
 
     def reset_adam(self):
         self.m.zero_(); self.v.zero_(); self.adam_t = 0
+        self.adam_t_dev.zero_()
 
     def adam_step(self, grads, lr, betas=(0.9, 0.999), eps=1e-8):
+        """One Adam update + weight re-layout.  The step count lives on the device so the call is
+        identical every step (hipGraph-capturable)."""
         self.adam_t += 1
-        _lib.check(self.lib.pinn_adam_step(_ptr(self.params), _ptr(grads), _ptr(self.m), _ptr(self.v),
-                                           self.num_params, lr, betas[0], betas[1], eps, self.adam_t, _stream()),
-                   "pinn_adam_step")
+        _lib.check(self.lib.pinn_adam_step_dev(_ptr(self.params), _ptr(grads), _ptr(self.m), _ptr(self.v),
+                                               self.num_params, lr, betas[0], betas[1], eps,
+                                               _ptr(self.adam_t_dev), _stream()), "pinn_adam_step_dev")
         self.prepare()
 
 
@@ -270,6 +274,7 @@ class PinnEngine:
         self.flat = torch.zeros(P + NSUMS, dtype=torch.float32, device=self.device)
         self.P, self.P1 = self.net.num_params, (self.net_e.num_params if self.net_e else 0)
         self.plan_f = self.plan_b = self.plan_s = self.plan_e = None
+        self._graphs = {}
         self.n_f_global = self.n_b_global = self.n_s_global = 0
         self.eq4_weight = 0.1
 
@@ -288,6 +293,7 @@ class PinnEngine:
 
     # ---- data ----
     def set_collocation(self, x, y, weights=None, n_global=None):
+        self._graphs.clear()      # captured steps hold the old plan's pointers
         self.plan_f = ResidualPlan(self.net, x, y, weights)
         self.n_f_global = int(n_global if n_global is not None else self.plan_f.n)
         if self.net_e is not None:
@@ -295,6 +301,7 @@ class PinnEngine:
             self.init_vis_t()
 
     def set_boundary(self, x, y, u, v, n_global=None):
+        self._graphs.clear()      # captured steps hold the old plan's pointers
         self.plan_b = ValuePlan(self.net, x, y, targets=[u, v, None])
         self.n_b_global = int(n_global if n_global is not None else self.plan_b.n)
 
@@ -302,6 +309,7 @@ class PinnEngine:
         if x is None:
             self.plan_s, self.n_s_global = None, 0
             return
+        self._graphs.clear()      # captured steps hold the old plan's pointers
         self.plan_s = ValuePlan(self.net, x, y, targets=[u, v, p])
         self.n_s_global = int(n_global if n_global is not None else self.plan_s.n)
 
@@ -381,8 +389,48 @@ class PinnEngine:
             self.net_e.adam_step(self.grads_e, lr)
 
     def step(self, lr):
-        self.loss_and_grad()
-        self.adam_step(lr)
+        """loss + gradient + (all-reduce) + Adam.  On one GPU the launch sequence is captured once per
+        (lr, schedule state) in a hipGraph and replayed: a 4x50 / 10 k-point step is otherwise launch-bound
+        (~25 launches).  NSFNET_GRAPH=0 disables it; with world_size > 1 it is opt-in (NSFNET_GRAPH=1)."""
+        if not self._graphs_enabled():
+            self.loss_and_grad()
+            self.adam_step(lr)
+            return
+        key = (float(lr), self.e_trainable, self.alpha_evm, self.alpha_b, self.alpha_e, self.alpha_s, self.scale,
+               self.n_f_global, self.n_b_global, self.n_s_global, self.Re, self.vis_t0, self.eq4_weight)
+        g = self._graphs.get(key)
+        if g is None:
+            # first use of this configuration: run it eagerly once (lazy host-side setup such as the
+            # supervised-target census happens here), then capture
+            self.loss_and_grad()
+            self.adam_step(lr)
+            if len(self._graphs) >= 8:
+                self._graphs.clear()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    self.loss_and_grad()
+                    self.adam_step(lr)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            # the capture itself does not execute; account for the host mirror it advanced
+            self.net.adam_t -= 1
+            if self.net_e is not None and self.e_trainable:
+                self.net_e.adam_t -= 1
+            self._graphs[key] = graph
+            return
+        g.replay()
+        self.net.adam_t += 1
+        if self.net_e is not None and self.e_trainable:
+            self.net_e.adam_t += 1
+
+    def _graphs_enabled(self):
+        import os
+        flag = os.environ.get("NSFNET_GRAPH")
+        if flag is not None:
+            return flag not in ("0", "", "false", "False")
+        return self.world_size == 1 and self.device.type == "cuda"
 
     # ---- inference (evaluate / test / predict) ----
     def predict(self, x, y, with_e=False):

@@ -294,10 +294,10 @@ class PysicsInformedNeuralNetwork:
             log_now = self.rank == 0 and (epoch_id == 0 or (epoch_id + 1) % interval == 0 or epoch_id == num_epoch - 1)
             save_now = self.rank == 0 and (epoch_id == 0 or epoch_id % 10000 == 0)
             if fused and not (log_now or save_now):
-                self.engine.loss_and_grad()
+                self.engine.step(self.opt.param_groups[0]['lr'])
             else:
                 loss, losses = loss_func()
-            self.engine.adam_step(self.opt.param_groups[0]['lr'])
+                self.engine.adam_step(self.opt.param_groups[0]['lr'])
             if scheduler:
                 scheduler.step()
             if log_now:

@@ -176,10 +176,10 @@ class PysicsInformedNeuralNetwork:
             log_now = self.log_every and epoch_id % self.log_every == 0
             save_now = self.save_every and epoch_id % self.save_every == 0
             if fused and not (log_now or save_now):
-                self.engine.loss_and_grad()          # no host sync, no scalar kernels
+                self.engine.step(lr)                 # no host sync; one hipGraph replay on a single GPU
             else:
                 loss, losses = loss_func()
-            self.engine.adam_step(lr)
+                self.engine.adam_step(lr)
             if scheduler:
                 scheduler.step()
             if log_now:
