@@ -126,9 +126,11 @@ int pinn_grad_reduce(pinn_net_t net, int nsrc, const pinn_plan_t* plans, void* c
 int pinn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n,
                    float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
-/* Same update with the step count in DEVICE memory (*step_counter = steps taken so far; the call uses
- * t = *step_counter + 1 for the bias corrections and then increments it), so that a whole training step can be
- * captured in a hipGraph and replayed without host-side scalars changing between steps. */
+/* Same update with the step count in DEVICE memory: step_counter points at TWO int64 words, [0] = steps taken
+ * so far, [1] = scratch that must be zero on entry (both zero to start / restart the schedule).  The call uses
+ * t = step_counter[0] + 1 for the bias corrections and increments step_counter[0] when its last workgroup is
+ * done, so a whole training step can be captured in a hipGraph and replayed with no host-side scalar changing
+ * between steps. */
 int pinn_adam_step_dev(float* params, const float* grads, float* m, float* v, int64_t n,
                        float lr, float beta1, float beta2, float eps, int64_t* step_counter, void* stream);
 

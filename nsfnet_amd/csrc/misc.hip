@@ -87,64 +87,90 @@ int launch_prep(const float* params, float* prep, int H, int HP, int L, int n_ou
 // (dW slabs of dw.hip, per-workgroup skinny accumulators of bwd.hip) over all
 // sources in a fixed order, in fp64.
 // ---------------------------------------------------------------------------
-__global__ void reduce_kernel(ReduceArgs a) {
+__global__ __launch_bounds__(512) void reduce_kernel(ReduceArgs a) {
+  // 64 consecutive flat parameters per workgroup; wave w of 8 sums sources w, w+8, ... (4 loads in flight),
+  // then the 8 wave sums are added in wave order: a fixed order for a given plan, whatever the launch.
+  __shared__ double part[8][64];
   const int H = a.H, HP = a.HP, L = a.L;
   const size_t P = flat_total(H, L, a.n_out);
-  size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  // decode
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t p = blockIdx.x * (size_t)64 + lane;
+  const bool live = p < P;
   int sgi = -1; int layer = -1; size_t slab_off = 0;
-  if (p < (size_t)2 * H) {
-    int o = (int)(p / 2), j = (int)(p % 2);
-    sgi = (j == 0 ? sg_w0x(HP, L) : sg_w0y(HP, L)) + o;
-  } else if (p < (size_t)3 * H) {
-    sgi = sg_db(HP, 0) + (int)(p - 2 * H);
-  } else if (p < flat_w(H, L)) {
-    size_t rel = p - (size_t)3 * H;
-    size_t per = (size_t)H * H + H;
-    int l = 1 + (int)(rel / per);
-    size_t q = rel % per;
-    if (q < (size_t)H * H) { layer = l; slab_off = (q / H) * HP + (q % H); }
-    else sgi = sg_db(HP, l) + (int)(q - (size_t)H * H);
-  } else {
-    size_t q = p - flat_w(H, L);
-    if (q < (size_t)a.n_out * H) sgi = sg_wout(HP, L) + (int)(q / H) * HP + (int)(q % H);
-    else sgi = sg_bout(HP, L) + (int)(q - (size_t)a.n_out * H);
-  }
-  double s = 0.0;
-  const int SG = sg_total(HP, L);
-  for (int k = 0; k < a.nsrc; ++k) {
-    const ReduceSrc& src = a.src[k];
-    if (layer >= 0) {
-      const float* base = src.slabs + (size_t)(layer - 1) * src.groups * HP * HP + slab_off;
-      for (int g = 0; g < src.groups; ++g) s += (double)base[(size_t)g * HP * HP];
+  if (live) {
+    if (p < (size_t)2 * H) {
+      int o = (int)(p / 2), j = (int)(p % 2);
+      sgi = (j == 0 ? sg_w0x(HP, L) : sg_w0y(HP, L)) + o;
+    } else if (p < (size_t)3 * H) {
+      sgi = sg_db(HP, 0) + (int)(p - 2 * H);
+    } else if (p < flat_w(H, L)) {
+      size_t rel = p - (size_t)3 * H;
+      size_t per = (size_t)H * H + H;
+      int l = 1 + (int)(rel / per);
+      size_t q = rel % per;
+      if (q < (size_t)H * H) { layer = l; slab_off = (q / H) * HP + (q % H); }
+      else sgi = sg_db(HP, l) + (int)(q - (size_t)H * H);
     } else {
-      for (int g = 0; g < src.nwg; ++g) s += (double)src.sg[(size_t)g * SG + sgi];
+      size_t q = p - flat_w(H, L);
+      if (q < (size_t)a.n_out * H) sgi = sg_wout(HP, L) + (int)(q / H) * HP + (int)(q % H);
+      else sgi = sg_bout(HP, L) + (int)(q - (size_t)a.n_out * H);
     }
   }
-  if (a.accumulate) a.grads[p] += (float)s; else a.grads[p] = (float)s;
+  double s = 0.0;
+  if (live) {
+    const size_t SG = sg_total(HP, L);
+    for (int k = 0; k < a.nsrc; ++k) {
+      const ReduceSrc& src = a.src[k];
+      const float* base; size_t stride; int n;
+      if (layer >= 0) { base = src.slabs + (size_t)(layer - 1) * src.groups * HP * HP + slab_off; stride = (size_t)HP * HP; n = src.groups; }
+      else { base = src.sg + sgi; stride = SG; n = src.nwg; }
+      int g = w;
+      for (; g + 24 < n; g += 32) {
+        float v0 = base[(size_t)g * stride], v1 = base[(size_t)(g + 8) * stride];
+        float v2 = base[(size_t)(g + 16) * stride], v3 = base[(size_t)(g + 24) * stride];
+        s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+      }
+      for (; g < n; g += 8) s += (double)base[(size_t)g * stride];
+    }
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && live) {
+    double t = part[0][lane];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += part[i][lane];
+    if (a.accumulate) a.grads[p] += (float)t; else a.grads[p] = (float)t;
+  }
 }
 
 int launch_reduce(const ReduceArgs& a, hipStream_t s) {
   size_t P = flat_total(a.H, a.L, a.n_out);
-  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(512), 0, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 // ---------------------------------------------------------------------------
-// loss partial sums [nparts][PINN_NLOSS] -> out[PINN_NLOSS] (fp64 accumulate, fixed order)
+// loss partial sums [nparts][PINN_NLOSS] -> out[PINN_NLOSS] (fp64 accumulate, fixed order:
+// 32 interleaved sub-sums per slot, added in index order)
 // ---------------------------------------------------------------------------
-__global__ void loss_sums_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
-  int k = threadIdx.x;
-  if (k >= PINN_NLOSS) return;
+__global__ __launch_bounds__(256) void loss_sums_kernel(const float* __restrict__ partials, int nparts, float* __restrict__ out) {
+  __shared__ double part[32][PINN_NLOSS];
+  const int k = threadIdx.x % PINN_NLOSS, j = threadIdx.x / PINN_NLOSS;
   double s = 0.0;
-  for (int i = 0; i < nparts; ++i) s += (double)partials[(size_t)i * PINN_NLOSS + k];
-  out[k] = (float)s;
+  for (int i = j; i < nparts; i += 32) s += (double)partials[(size_t)i * PINN_NLOSS + k];
+  part[j][k] = s;
+  __syncthreads();
+  if (threadIdx.x < PINN_NLOSS) {
+    double t = part[0][k];
+    for (int i = 1; i < 32; ++i) t += part[i][k];
+    out[k] = (float)t;
+  }
 }
 
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(loss_sums_kernel, dim3(1), dim3(64), 0, s, partials, nparts, out);
+  static_assert(PINN_NLOSS * 32 == 256, "loss_sums_kernel layout");
+  hipLaunchKernelGGL(loss_sums_kernel, dim3(1), dim3(256), 0, s, partials, nparts, out);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -172,8 +198,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // training step can be captured once in a hipGraph and replayed: no host scalar changes between steps.
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                const long long* __restrict__ step_counter) {
-  const double t = (double)(*step_counter + 1);
+                                long long* step_counter) {
+  const double t = (double)(__atomic_load_n(step_counter, __ATOMIC_RELAXED) + 1);
   const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
   const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -184,8 +210,17 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
     p[i] = p[i] - step_size * (mi / denom);
     m[i] = mi; v[i] = vi;
   }
+  // the last workgroup to get here has seen every other one read the counter: it advances it
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(step_counter + 1);
+    __threadfence();
+    if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1) {
+      *ticket = 0;
+      step_counter[0] = step_counter[0] + 1;
+    }
+  }
 }
-__global__ void counter_inc_kernel(long long* c) { *c += 1; }
 
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                     float eps, long long* step_counter, hipStream_t s) {
@@ -193,7 +228,6 @@ int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float 
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, step_counter);
-  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, s, step_counter);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

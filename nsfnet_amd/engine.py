@@ -21,10 +21,11 @@ FLD = dict(u=0, v=1, u_x=2, u_y=3, v_x=4, v_y=5, eq1=6, eq2=7, eq3=8, eq4=9, p=1
 FLD_COUNT = 11
 
 # slots of the per-step sums vector (all-reduced together with the gradients)
-S_EQ = 0        # 0..3  sum w*eq_k^2
-S_BC = 4        # 4,5   sum (u-u_b)^2, sum (v-v_b)^2
-S_SUP = 8       # 8..10 sum sq err u,v,p ; 11 = number of finite p targets
-NSUMS = 16
+# (three blocks of NLOSS, each written whole by one loss-sum launch: no per-step zeroing or copies)
+S_EQ = 0        # 0..3   sum w*eq_k^2
+S_BC = 8        # 8,9    sum (u-u_b)^2, sum (v-v_b)^2
+S_SUP = 16      # 16..18 sum sq err u,v,p ; 19 = number of finite p targets
+NSUMS = 24
 
 
 def _ptr(t):
@@ -75,7 +76,7 @@ class DeviceNet:
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.adam_t = 0                                                   # steps taken (host mirror)
-        self.adam_t_dev = torch.zeros(1, dtype=torch.int64, device=device)   # the counter the kernel uses
+        self.adam_t_dev = torch.zeros(2, dtype=torch.int64, device=device)   # [count, scratch] the kernel uses
 
     def __del__(self):
         try:
@@ -275,6 +276,9 @@ class PinnEngine:
         self.P, self.P1 = self.net.num_params, (self.net_e.num_params if self.net_e else 0)
         self.plan_f = self.plan_b = self.plan_s = self.plan_e = None
         self._graphs = {}
+        self._side = None
+        import os
+        self._overlap = os.environ.get("NSFNET_OVERLAP_BC", "1") not in ("0", "", "false")
         self.n_f_global = self.n_b_global = self.n_s_global = 0
         self.eq4_weight = 0.1
 
@@ -308,6 +312,7 @@ class PinnEngine:
     def set_supervised(self, x, y, u, v, p=None, n_global=None):
         if x is None:
             self.plan_s, self.n_s_global = None, 0
+            self.sums[S_SUP:S_SUP + NLOSS].zero_()
             return
         self._graphs.clear()      # captured steps hold the old plan's pointers
         self.plan_s = ValuePlan(self.net, x, y, targets=[u, v, p])
@@ -322,31 +327,42 @@ class PinnEngine:
     def loss_and_grad(self):
         f, b = self.plan_f, self.plan_b
         sums = self.sums
-        sums.zero_()
+        s = self.plan_s if (self.plan_s is not None and self.alpha_s != 0.0) else None
+        n_p = self._n_p_valid_global() if s is not None else 0
+        # The value-mode chains (boundary / supervised points: a few thousand points, latency-bound
+        # kernels) are independent of the collocation chain until the gradient assembly: they run on a
+        # second HIP stream beside it.
+        main = side = None
+        if self.device.type == "cuda" and self._overlap:
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream(main)
+            side.wait_stream(main)
+            torch.cuda.set_stream(side)
+        try:
+            cb = 2.0 * self.alpha_b / self.n_b_global
+            b.forward(coef=(cb, cb, 0.0), save=True, sums_out=sums[S_BC:S_BC + NLOSS])
+            b.backward()
+            if s is not None:
+                # per-output means: u,v over all supervised points, p over its finite targets (ev:399-411)
+                cs = 2.0 * self.alpha_s / self.n_s_global
+                s.forward(coef=(cs, cs, (2.0 * self.alpha_s / n_p) if n_p > 0 else 0.0), save=True,
+                          sums_out=sums[S_SUP:S_SUP + NLOSS])
+                s.backward()
+        finally:
+            if side is not None:
+                torch.cuda.set_stream(main)
         e = None
         if self.net_e is not None:
             self.plan_e.forward(save=self.e_trainable)
             e = self.plan_e.pred[0]
         f.forward(self.Re, e=e, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
                   sums_out=sums[S_EQ:S_EQ + NLOSS])
-        cb = 2.0 * self.alpha_b / self.n_b_global
-        b.forward(coef=(cb, cb, 0.0), save=True)
-        sums[S_BC:S_BC + 2].copy_(b.sums[0:2])
-        plans = [f, b]
-        s = self.plan_s
-        if s is not None and self.alpha_s != 0.0:
-            # per-output means: u,v over all supervised points, p over its finite targets (ev:399-411)
-            cs = 2.0 * self.alpha_s / self.n_s_global
-            n_p = self._n_p_valid_global()
-            s.forward(coef=(cs, cs, (2.0 * self.alpha_s / n_p) if n_p > 0 else 0.0), save=True)
-            sums[S_SUP:S_SUP + 4].copy_(s.sums[0:4])
-            plans.append(s)
         c = 2.0 * self.alpha_e / self.n_f_global
         coef_eq = (c, c, c, c * self.eq4_weight if self.net_e is not None else 0.0)
         f.backward(self.Re, coef_eq, e=e, scale=self.scale, want_ebar=self.e_trainable)
-        b.backward()
-        if len(plans) == 3:
-            s.backward()
+        if side is not None:
+            main.wait_stream(side)
+        plans = [f, b] if s is None else [f, b, s]
         grad_reduce(self.net, plans, self.grads)
         if self.net_e is not None:
             if self.e_trainable:
@@ -356,6 +372,13 @@ class PinnEngine:
                 self.grads_e.zero_()
         if self.world_size > 1:
             torch.distributed.all_reduce(self.flat, group=self.pg)
+
+    def _side_stream(self, main):
+        """The stream the value-mode chains run on.  Inside a graph capture it must be a stream that is
+        not already capturing something else; one persistent stream per engine serves both cases."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _n_p_valid_global(self):
         if getattr(self, "_n_p_valid", None) is None:
@@ -389,9 +412,10 @@ class PinnEngine:
             self.net_e.adam_step(self.grads_e, lr)
 
     def step(self, lr):
-        """loss + gradient + (all-reduce) + Adam.  On one GPU the launch sequence is captured once per
-        (lr, schedule state) in a hipGraph and replayed: a 4x50 / 10 k-point step is otherwise launch-bound
-        (~25 launches).  NSFNET_GRAPH=0 disables it; with world_size > 1 it is opt-in (NSFNET_GRAPH=1)."""
+        """loss + gradient + (all-reduce) + Adam.  With NSFNET_GRAPH=1 the launch sequence is captured
+        once per (lr, schedule state) in a hipGraph and replayed.  Opt-in: measured on MI355X the eager
+        launch sequence (~14 launches, all asynchronous) already keeps the GPU busy down to the 4x50 /
+        10 k-point step (0.12 ms), and replay is 0-6 % slower; it pays only when the host is contended."""
         if not self._graphs_enabled():
             self.loss_and_grad()
             self.adam_step(lr)
@@ -428,9 +452,7 @@ class PinnEngine:
     def _graphs_enabled(self):
         import os
         flag = os.environ.get("NSFNET_GRAPH")
-        if flag is not None:
-            return flag not in ("0", "", "false", "False")
-        return self.world_size == 1 and self.device.type == "cuda"
+        return flag is not None and flag not in ("0", "", "false", "False") and self.device.type == "cuda"
 
     # ---- inference (evaluate / test / predict) ----
     def predict(self, x, y, with_e=False):

@@ -24,7 +24,7 @@ class FakeDeviceNet(eng.DeviceNet):
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.adam_t = 0
-        self.adam_t_dev = torch.zeros(1, dtype=torch.int64)
+        self.adam_t_dev = torch.zeros(2, dtype=torch.int64)
 
     def __del__(self):
         pass

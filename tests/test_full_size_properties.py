@@ -93,7 +93,7 @@ def test_directional_derivative(base):
         E.net.set_flat(torch.tensor((base["flat"].astype(np.float64) + sgn * eps * d).astype(np.float32)))
         E.loss_and_grad()
         s = E.sums.cpu().numpy().astype(np.float64)
-        vals.append(10.0 * (s[4] + s[5]) / 2052 + (s[0] + s[1] + s[2]) / base["x"].size)
+        vals.append(10.0 * (s[8] + s[9]) / 2052 + (s[0] + s[1] + s[2]) / base["x"].size)
     E.net.set_flat(torch.tensor(base["flat"]))
     fd = (vals[0] - vals[1]) / (2 * eps)
     gd = float(base["grads"] @ d)

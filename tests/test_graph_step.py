@@ -23,7 +23,7 @@ def _run_nsfnet(monkeypatch, graph, steps):
     P.train(num_epoch=steps, lr=1e-3)
     P.train(num_epoch=steps, lr=2e-4)        # second stage: new lr -> a second captured graph
     torch.cuda.synchronize()
-    return P.engine.net.params.cpu().numpy().copy(), P.engine.net.adam_t, int(P.engine.net.adam_t_dev.item())
+    return P.engine.net.params.cpu().numpy().copy(), P.engine.net.adam_t, int(P.engine.net.adam_t_dev[0].item())
 
 
 def test_graph_replay_is_bit_identical_to_eager(monkeypatch, tmp_path):

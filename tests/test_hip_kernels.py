@@ -68,7 +68,7 @@ def test_residual_and_bc_gradients(L, H, N, Nb):
         assert _rel_max(f.field(name).cpu().numpy(), ref) < 2e-5, name
     sums = E.sums.cpu().numpy()
     np.testing.assert_allclose(sums[0:3], r["sums"], rtol=1e-5)
-    np.testing.assert_allclose(sums[4:6], b["sums"], rtol=1e-5)
+    np.testing.assert_allclose(sums[8:10], b["sums"], rtol=1e-5)
     np.testing.assert_allclose(E.plan_b.pred.cpu().numpy()[:2].T, b["pred"][:, :2], rtol=0, atol=2e-6)
     g = E.grads.cpu().numpy()
     assert _rel_l2(g, r["grad"] + b["grad"]) < 1e-4
