@@ -12,13 +12,14 @@
 // different precisions interoperate.
 #include "kernels.h"
 #include "bf16_util.h"
+#include <type_traits>
 
 // COLS = 128: tile = 32 points x 4 streams, one workgroup per CU at HP = 256.
 // COLS = 64 : tile = 16 points x 4 streams (two streams per 32-column accumulator tile, exchanged
 //             with v_permlane16_swap before the lane-local epilogue); half the LDS and <= 128 VGPRs,
 //             so two workgroups share a CU and cover each other's epilogue / spill / MFMA phases.
 template <int HP, int NS, int TERMS, int COLS>
-__global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd_bf16_kernel(FwdArgs a) {
+__global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 1) void fwd_bf16_kernel(FwdArgs a) {
   constexpr int PPL = COLS / 4, NTL = COLS / 32;
   using XI = XImg<HP, PPL>;
   constexpr int NW = HP / 32, NT = HP * 2, KS = HP / 16;
@@ -81,13 +82,40 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
         }
       }
     }
-    for (int l = 0; l < L; ++l) {
-      // Next layer's weight fragments and bias are requested BEFORE this layer's activation
+    // Layer loop as a ROTATED slot schedule.  The workgroup's waves split into group A (the first NA
+    // waves = the low KLO k-steps' features) and group B (the rest); B runs one barrier interval behind A:
+    //     slot:   0        1          2          3          4          5       ...
+    //     A:    EPI(0)   GEMMlo(1)  GEMMhi(1)  EPI(1)     GEMMlo(2)  GEMMhi(2)
+    //     B:     -       EPI(0)     GEMMlo(1)  GEMMhi(1)  EPI(1)     GEMMlo(2)
+    // GEMMlo / GEMMhi are the k-steps fed by A's / B's features of the previous layer.  Each SIMD holds
+    // one A and one B wave (waves w and w+4 share a SIMD), so in two slots of three one of them issues
+    // MFMAs while its partner runs the VALU chain-rule epilogue + spill: the matrix pipe and the vector
+    // pipe overlap without a second activation image in LDS (EPI overwrites its own half of the image
+    // in place: every reader of that half is two slots behind it) and without halving the tile (each
+    // streamed weight fragment still feeds 12 MFMAs).  Workgroups of <= 4 waves share their CU with
+    // other workgroups, which already gives that overlap: they keep the plain EPI / GEMM alternation.
+    constexpr bool ROT = NW >= 5;
+    constexpr int NA = ROT ? 4 : NW;
+    constexpr int KLO = 2 * NA;                     // k-steps fed by group A's features
+    constexpr int PERIOD = ROT ? 3 : 2;
+    const int role = ROT ? (w >= NA ? 1 : 0) : 0;
+    const int last_j = PERIOD * (L - 1);            // local step of EPI(L-1)
+    u32x4 wh[RING], wl[RING];
+    // B fragment of accumulator tile j: plane j (128 cols) or plane 2j+hi (64 cols), column pp
+    const unsigned char* Xl = Xb + (COLS == 128 ? 0 : hi * XI::PLANE * 2);
+    constexpr int TSTR = (COLS == 128 ? 1 : 2) * XI::PLANE * 2;
+    for (int slot = 0; slot <= last_j + (ROT ? 1 : 0); ++slot) {
+      const int j = slot - role;
+      const int ph = j <= 0 ? PERIOD - 1 : (j - 1) % PERIOD;      // PERIOD-1 = EPI, 0 = GEMM lo, 1 = GEMM hi
+      const int l = j <= 0 ? 0 : (j - 1) / PERIOD + (ph == PERIOD - 1 ? 1 : 0);   // layer whose EPI runs / that feeds the GEMM
+      if (j < 0 || j > last_j) {
+        // idle slot of the lagging / leading group
+      } else if (ph == PERIOD - 1) {
+      // ---------------- EPI(l): tanh chain rule on the accumulators, restage, spill ----------------
+      // Next layer's weight fragments are requested BEFORE this layer's activation
       // stores: vmcnt retires in order, so a weight load issued behind the 16 S stores would
       // make the MFMA loop wait for the whole HBM store burst.
-      // (only the first PRE k-steps; the rest stream through a small register ring inside the MFMA
-      // loop so that the B fragments can be double-buffered: see gemm_ring below)
-      u32x4 wh[RING], wl[RING];
+      // (only the first PRE k-steps; the rest stream through a small register ring inside the MFMA loop)
       const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wf(HP, l + 1 < L ? l + 1 : 1)) + (size_t)w * KS * 64 + lane;
       if (l < L - 1) {
 #pragma unroll
@@ -123,8 +151,8 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
 #ifndef PINN_NO_NT   // streamed once: keep the spill out of L2's way (measured -3 % on the kernel)
           __builtin_nontemporal_store(s0, Sg + 0 * (HP / 4) * PPL);
           __builtin_nontemporal_store(s1, Sg + 1 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
+          if (!(a.dbg & 32)) __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
+          if (!(a.dbg & 48)) __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
 #else
           Sg[0 * (HP / 4) * PPL] = s0;
           Sg[1 * (HP / 4) * PPL] = s1;
@@ -195,61 +223,76 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
           }
         }
       }
-      __syncthreads();
-      if (l == L - 1) break;
-      // ------------- hidden GEMM l+1 on bf16 MFMA -------------
-      {
+      // The accumulators of the NEXT GEMM are initialised here (bias / zero), not at its start: that ends the
+      // old accumulators' live range inside this branch, so the epilogue's temporaries can reuse their
+      // registers as the quads retire (the slot loop otherwise keeps all 64 live across the branch).
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float b = biasL[(l + 1) * HP + ob + mfma_row(r, h)];
+          float b = biasL[(l + 1 < L ? l + 1 : l) * HP + ob + mfma_row(r, h)];
           if (NS == 4) {
             if (COLS == 128) { acc[0][r] = b; acc[1][r] = 0.f; acc[2 % NTL][r] = 0.f; acc[3 % NTL][r] = 0.f; }
             else { acc[0][r] = hi ? 0.f : b; acc[1][r] = 0.f; }
           } else {
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) acc[j][r] = b;
+            for (int jj = 0; jj < NTL; ++jj) acc[jj][r] = b;
           }
         }
-        // B fragment of accumulator tile j: plane j (128 cols) or plane 2j+hi (64 cols), column pp
-        const unsigned char* Xl = Xb + (COLS == 128 ? 0 : hi * XI::PLANE * 2);
-        constexpr int TSTR = (COLS == 128 ? 1 : 2) * XI::PLANE * 2;
-        u32x4 bh[NTL], bo[NTL];
-        {
-          const int off0 = XI::chunk_off(pp, h);
 #pragma unroll
-          for (int j = 0; j < NTL; ++j) {
-            bh[j] = *reinterpret_cast<const u32x4*>(Xl + j * TSTR + off0);
-            if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off0);
-          }
-        }
-        if (!(a.dbg & 1))
+      for (int s = PRE; s < RING; ++s) { wh[s] = u32x4{0u, 0u, 0u, 0u}; if (TERMS == 3) wl[s] = u32x4{0u, 0u, 0u, 0u}; }
+      } else {
+        // ---------------- hidden GEMM l+1 on bf16 MFMA: k-steps [0, KLO) or [KLO, KS) ----------------
+        const u32x4* wf = reinterpret_cast<const u32x4*>(P + prep_wf(HP, l + 1)) + (size_t)w * KS * 64 + lane;
+        // one k-step range, fully unrolled (static ring indices); B fragments double-buffered inside it
+        auto gemm_range = [&](auto k0c, auto k1c) {
+          constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
+          if (K0 >= K1) return;
+          // the swizzled per-k-step LDS offsets are recomputed here (2 VALU each): laundering the column
+          // keeps the compiler from hoisting all KS of them out of the slot loop into spilled registers
+          int ppv = pp;
+          asm volatile("" : "+v"(ppv));
+          u32x4 bh[NTL], bo[NTL];
+          {
+            const int off0 = XI::chunk_off(ppv, 2 * K0 + h);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          if (s + PRE < KS && !(a.dbg & 8)) {     // stream the weight fragments PRE k-steps ahead
-            wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
-            if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
-          }
-          u32x4 nh[NTL], no[NTL];
-          if (s + 1 < KS) {       // next k-step's B fragments in flight during this step's MFMAs
-            const int off = XI::chunk_off(pp, 2 * (s + 1) + h);
-#pragma unroll
-            for (int j = 0; j < NTL; ++j) {
-              nh[j] = *reinterpret_cast<const u32x4*>(Xl + j * TSTR + off);
-              if (TERMS == 3) no[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off);
+            for (int jj = 0; jj < NTL; ++jj) {
+              bh[jj] = *reinterpret_cast<const u32x4*>(Xl + jj * TSTR + off0);
+              if (TERMS == 3) bo[jj] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + jj * TSTR + off0);
             }
           }
+          if (!(a.dbg & 1))
 #pragma unroll
-          for (int j = 0; j < NTL; ++j) {
-            if (TERMS == 3) {
-              acc[j] = mfma_bf16(wh[s % RING], bo[j], acc[j]);
-              acc[j] = mfma_bf16(wl[s % RING], bh[j], acc[j]);
+          for (int s = K0; s < K1; ++s) {
+            if (s + PRE < KS && !(a.dbg & 8)) {     // stream the weight fragments PRE k-steps ahead
+              wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
+              if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
             }
-            acc[j] = mfma_bf16(wh[s % RING], bh[j], acc[j]);
-          }
-          if (s + 1 < KS) {
+            u32x4 nh[NTL], no[NTL];
+            if (s + 1 < K1) {       // next k-step's B fragments in flight during this step's MFMAs
+              const int off = XI::chunk_off(ppv, 2 * (s + 1) + h);
 #pragma unroll
-            for (int j = 0; j < NTL; ++j) { bh[j] = nh[j]; if (TERMS == 3) bo[j] = no[j]; }
+              for (int jj = 0; jj < NTL; ++jj) {
+                nh[jj] = *reinterpret_cast<const u32x4*>(Xl + jj * TSTR + off);
+                if (TERMS == 3) no[jj] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + jj * TSTR + off);
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NTL; ++jj) {
+              if (TERMS == 3) {
+                acc[jj] = mfma_bf16(wh[s % RING], bo[jj], acc[jj]);
+                acc[jj] = mfma_bf16(wl[s % RING], bh[jj], acc[jj]);
+              }
+              acc[jj] = mfma_bf16(wh[s % RING], bh[jj], acc[jj]);
+            }
+            if (s + 1 < K1) {
+#pragma unroll
+              for (int jj = 0; jj < NTL; ++jj) { bh[jj] = nh[jj]; if (TERMS == 3) bo[jj] = no[jj]; }
+            }
           }
+        };
+        if (ph == 0) {
+          gemm_range(std::integral_constant<int, 0>{}, std::integral_constant<int, KLO>{});
+        } else {
+          gemm_range(std::integral_constant<int, KLO>{}, std::integral_constant<int, KS>{});
         }
       }
       __syncthreads();

@@ -30,11 +30,12 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
   lo[1] = pack_bf16(x2 - bf_lo_f(h1), x3 - bf_hi_f(h1));
 }
 
-// tanh for the bf16 modes: 1 - 2/(exp(2z)+1) on v_exp_f32 / v_rcp_f32 (abs. error ~1e-7,
-// far below the bf16x3 operand rounding); saturates correctly at +-inf.
+// tanh for the bf16 modes: 1 - 2/(exp(2z)+1) on v_exp_f32 / v_rcp_f32 (both 1 ulp: abs. error
+// ~2e-7, far below the bf16x3 operand rounding); saturates correctly at +-inf.  The bare v_rcp_f32
+// matters: an IEEE 1/x costs 11 VALU instructions, a fifth of the whole chain-rule epilogue.
 __device__ __forceinline__ float fast_tanh(float z) {
   float e = __expf(2.f * z);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {

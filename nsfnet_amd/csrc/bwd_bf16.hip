@@ -9,7 +9,7 @@
 #include "reduce_util.h"
 
 template <int HP, int NS, int TERMS, int COLS>
-__global__ __launch_bounds__(HP * 2) void bwd_bf16_kernel(BwdArgs a) {
+__global__ __launch_bounds__(HP * 2, 2) void bwd_bf16_kernel(BwdArgs a) {
   constexpr int PPL = COLS / 4, NTL = COLS / 32;
   using XI = XImg<HP, PPL>;
   constexpr int NT = HP * 2, KS = HP / 16;
