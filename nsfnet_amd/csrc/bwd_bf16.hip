@@ -130,38 +130,58 @@ __global__ __launch_bounds__(HP * 2, 2) void bwd_bf16_kernel(BwdArgs a) {
         f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * PPL), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * PPL);
         f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * PPL), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * PPL);
         f32x4 z0, z1, z2, z3;
+        // branch-free chain for the four features (the layer-specific skinny-gradient terms follow below,
+        // once per quad: a branch per element splits this into blocks the scheduler cannot pack)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int o = ob + 8 * g + 4 * h + e;
           float t = s0[e], zx = s1[e], zy = s2[e], zd = s3[e];
           float d1 = 1.f - t * t;
           float d2 = -2.f * t * d1;
           float d3 = -2.f * d1 * (1.f - 3.f * t * t);
-          float wo0 = 0.f, wo1 = 0.f, wo2 = 0.f;
-          if (l == L - 1) {   // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
-            float ax = d1 * zx, ay = d1 * zy, ad = d2 * (zx * zx + zy * zy) + d1 * zd;
-            wo0 = oa[0][0] * t + oa[0][1] * ax + oa[0][2] * ay + oa[0][3] * ad;
-            wo1 = oa[1][0] * t + oa[1][1] * ax + oa[1][2] * ay + oa[1][3] * ad;
-            wo2 = oa[2][0] * t + oa[2][1] * ax + oa[2][2] * ay + oa[2][3] * ad;
-          }
           float zbx = d1 * gx[e] + 2.f * d2 * zx * gd[e];
           float zby = d1 * gy[e] + 2.f * d2 * zy * gd[e];
           float zbd = d1 * gd[e];
           float zb = d1 * ga[e] + d2 * (zx * gx[e] + zy * gy[e]) + (d3 * (zx * zx + zy * zy) + d2 * zd) * gd[e];
           z0[e] = zb; z1[e] = zbx; z2[e] = zby; z3[e] = zbd;
-          float dbv = sum_cols<PPL>(zb);
-          if (pp == 0) sgacc[sg_db(HP, l) + o] += dbv;
+        }
+        f32x4 wo0v, wo1v, wo2v, dwxv, dwyv;      // per-element column terms of the skinny gradients
+        if (l == L - 1) {   // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = s0[e], zx = s1[e], zy = s2[e], zd = s3[e];
+            float d1 = 1.f - t * t, d2 = -2.f * t * d1;
+            float ax = d1 * zx, ay = d1 * zy, ad = d2 * (zx * zx + zy * zy) + d1 * zd;
+            wo0v[e] = oa[0][0] * t + oa[0][1] * ax + oa[0][2] * ay + oa[0][3] * ad;
+            wo1v[e] = oa[1][0] * t + oa[1][1] * ax + oa[1][2] * ay + oa[1][3] * ad;
+            wo2v[e] = oa[2][0] * t + oa[2][1] * ax + oa[2][2] * ay + oa[2][3] * ad;
+          }
+        }
+        if (l == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dwxv[e] = z0[e] * px[0] + z1[e]; dwyv[e] = z0[e] * py[0] + z2[e]; }
+        }
+        // column sums of the four features at once; lane pp == e of each 16/32-lane group commits feature e
+        {
+          const int o = ob + 8 * g + 4 * h + (pp & 3);
+          const float dbv = sum_cols4<PPL>(z0[0], z0[1], z0[2], z0[3], lane);
+          float w0 = 0.f, w1 = 0.f, w2 = 0.f, dx = 0.f, dy = 0.f;
           if (l == L - 1) {
-            wo0 = sum_cols<PPL>(wo0); wo1 = sum_cols<PPL>(wo1); wo2 = sum_cols<PPL>(wo2);
-            if (pp == 0) {
-              sgacc[sg_wout(HP, L) + o] += wo0;
-              sgacc[sg_wout(HP, L) + HP + o] += wo1;
-              sgacc[sg_wout(HP, L) + 2 * HP + o] += wo2;
-            }
+            w0 = sum_cols4<PPL>(wo0v[0], wo0v[1], wo0v[2], wo0v[3], lane);
+            w1 = sum_cols4<PPL>(wo1v[0], wo1v[1], wo1v[2], wo1v[3], lane);
+            w2 = sum_cols4<PPL>(wo2v[0], wo2v[1], wo2v[2], wo2v[3], lane);
           }
           if (l == 0) {
-            float dwx = sum_cols<PPL>(zb * px[0] + zbx), dwy = sum_cols<PPL>(zb * py[0] + zby);
-            if (pp == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
+            dx = sum_cols4<PPL>(dwxv[0], dwxv[1], dwxv[2], dwxv[3], lane);
+            dy = sum_cols4<PPL>(dwyv[0], dwyv[1], dwyv[2], dwyv[3], lane);
+          }
+          if (pp < 4) {
+            sgacc[sg_db(HP, l) + o] += dbv;
+            if (l == L - 1) {
+              sgacc[sg_wout(HP, L) + o] += w0;
+              sgacc[sg_wout(HP, L) + HP + o] += w1;
+              sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+            }
+            if (l == 0) { sgacc[sg_w0x(HP, L) + o] += dx; sgacc[sg_w0y(HP, L) + o] += dy; }
           }
         }
         if (l > 0) {

@@ -23,3 +23,31 @@ __device__ __forceinline__ float sum32(float v) {
 }
 template <int W>
 __device__ __forceinline__ float sum_cols(float v) { return W == 32 ? sum32(v) : sum16(v); }
+
+// Four values per lane (the four features of a register quad) summed over W = 16 / 32 lanes at once:
+// the first two butterfly steps also TRANSPOSE, so each lane carries one value from then on and lane
+// (l & 3) == e ends up with the full sum of v[e].  14 VALU instead of 4 x 9, and the caller can
+// commit all four sums with one masked LDS update (lanes 0..3 of the group) instead of four.
+__device__ __forceinline__ float sum_cols4_t(float v0, float v1, float v2, float v3, int lane, bool w32) {
+  const bool p1 = lane & 1, p2 = lane & 2;
+  // xor 1: keep elements {p1, 2 + p1}, hand the other two to the neighbour
+  float k0 = p1 ? v1 : v0, s0 = p1 ? v0 : v1;
+  float k1 = p1 ? v3 : v2, s1 = p1 ? v2 : v3;
+  float x0 = k0 + dpp_mov<0xB1>(s0);    // quad_perm [1,0,3,2]
+  float x1 = k1 + dpp_mov<0xB1>(s1);
+  // xor 2: keep element 2 * p2 + p1
+  float k = p2 ? x1 : x0, sd = p2 ? x0 : x1;
+  float y = k + dpp_mov<0x4E>(sd);      // quad_perm [2,3,0,1]
+  // the four quads of the 16-lane row (same l & 3): rotate by 8 and by 4
+  y += dpp_mov<0x128>(y);               // row_ror:8
+  y += dpp_mov<0x124>(y);               // row_ror:4
+  if (w32) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return y;
+}
+template <int W>
+__device__ __forceinline__ float sum_cols4(float v0, float v1, float v2, float v3, int lane) {
+  return sum_cols4_t(v0, v1, v2, v3, lane, W == 32);
+}
