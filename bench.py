@@ -199,6 +199,10 @@ def main():
 
     def kernel_report(E_, prec, ms_step):
         f = E_.plan_f
+        n_launch = n_local
+        if hasattr(f, "chunks"):          # $NSFNET_CHUNK_POINTS: time one pass (the first, largest chunk)
+            f = f.chunks[0]
+            n_launch = f.n
         c = 2.0 / n_global
         reps = max(3, min(10, args.steps))
         t_fwd = time_kernel(lambda: f.forward(Re, save=True), reps)
@@ -206,7 +210,7 @@ def main():
         t_dw = time_kernel(lambda: f.backward(Re, (c, c, c, 0.0), phases=2), reps)
         log("[%s] kernel ms: fwd %.3f bwd %.3f dw %.3f" % (prec, t_fwd, t_bwd, t_dw))
         pw = weight_count(L, H)
-        flops_each = 8.0 * pw * n_local        # fwd, dX sweep and dW GEMM each carry 2*4*P_w FLOP per point
+        flops_each = 8.0 * pw * n_launch       # fwd, dX sweep and dW GEMM each carry 2*4*P_w FLOP per point
         wide = H > 256 or (H > 224 and prec == "fp32")      # 64-column-tile kernels (csrc/capi.hip pick_wide)
         names = {"fp32": ("fwd_wide_kernel", "bwd_wide_kernel", "dw_wide_kernel") if wide else ("fwd_kernel", "bwd_kernel", "dw_kernel"),
                  "bf16x3": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel"),
@@ -215,13 +219,13 @@ def main():
         dom = max(kernels, key=kernels.get)
         achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
         peak = MFMA_PEAK_TFLOPS[prec]
-        traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid) == (6, 256, 600) else None
+        traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid, n_launch) == (6, 256, 600, n_local) else None
         return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                     traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[prec],
                     mfma_issue_frac=achieved * MFMA_PER_PRODUCT[prec] / peak,
                     kernel_ms={k: round(v, 4) for k, v in kernels.items()},
                     step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12,
-                    forward_only_evals_per_s=n_local / (t_fwd * 1e-3))
+                    forward_only_evals_per_s=n_launch / (t_fwd * 1e-3))
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps

@@ -140,7 +140,7 @@ class DeviceNet:
 class PointPlan:
     """A fixed set of points evaluated by one DeviceNet (residual or value mode)."""
 
-    def __init__(self, net, x, y, streams, with_backward=True):
+    def __init__(self, net, x, y, streams, with_backward=True, ws=None):
         self.lib, self.net, self.streams = net.lib, net, streams
         dev = net.device
         self.x = torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(-1)).to(dev).contiguous()
@@ -154,7 +154,9 @@ class PointPlan:
         self.npad = int(self.lib.pinn_plan_padded_points(h))
         self.with_backward = with_backward
         nbytes = int(self.lib.pinn_plan_workspace_bytes(h, 1 if with_backward else 0))
-        self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+        if ws is not None and ws.numel() < nbytes:
+            raise ValueError("shared workspace too small: %d < %d bytes" % (ws.numel(), nbytes))
+        self.ws = ws if ws is not None else torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
         self.sums = torch.zeros(NLOSS, dtype=torch.float32, device=dev)
 
     def __del__(self):
@@ -167,8 +169,8 @@ class PointPlan:
 
 
 class ResidualPlan(PointPlan):
-    def __init__(self, net, x, y, weights=None, with_backward=True):
-        super().__init__(net, x, y, 4, with_backward)
+    def __init__(self, net, x, y, weights=None, with_backward=True, ws=None):
+        super().__init__(net, x, y, 4, with_backward, ws)
         dev = net.device
         self.fields = torch.zeros(FLD_COUNT, self.npad, dtype=torch.float32, device=dev)
         self.w = None if weights is None else torch.as_tensor(
@@ -199,6 +201,61 @@ class ResidualPlan(PointPlan):
 
     def field(self, name):
         return self.fields[FLD[name], :self.n]
+
+
+class ChunkedResidual:
+    """Collocation set processed in passes of `chunk_points` points that SHARE one activation workspace
+    (forward -> reverse sweep -> gradient assembly per pass, gradients and loss sums accumulated), for
+    point sets whose saved activations would not fit in HBM at once - the mini-batching of the
+    reference's roadmap (ev-NSFnet/README.md:118; its `batchsize` argument is dead).  Full-batch
+    semantics are unchanged: every pass uses the global normalisation.  Presents the attributes of a
+    ResidualPlan (field(), vis_t, vis_t_minus, ebar, n)."""
+
+    ALIGN = 128      # chunk boundaries on a multiple of every tile size (16 / 32 / 128 points)
+
+    def __init__(self, net, x, y, weights=None, chunk_points=1 << 20):
+        x = np.asarray(x, dtype=np.float32).reshape(-1)
+        y = np.asarray(y, dtype=np.float32).reshape(-1)
+        w = None if weights is None else np.asarray(weights, dtype=np.float32).reshape(-1)
+        if w is not None and w.size != x.size:
+            raise ValueError("weights must have one entry per collocation point")
+        self.net, self.n = net, x.size
+        chunk = max(self.ALIGN, int(chunk_points) // self.ALIGN * self.ALIGN)
+        self.bounds = [(a, min(a + chunk, self.n)) for a in range(0, self.n, chunk)]
+        self.chunks, ws = [], None
+        for a, b in self.bounds:       # the first pass is the largest: it sizes the shared workspace
+            c = ResidualPlan(net, x[a:b], y[a:b], None if w is None else w[a:b], ws=ws)
+            ws = c.ws
+            self.chunks.append(c)
+        self.npad = sum(c.npad for c in self.chunks)
+        self.w = None if w is None else torch.cat([c.w for c in self.chunks])
+        self.tmp_sums = torch.zeros(NLOSS, dtype=torch.float32, device=net.device)
+
+    def field(self, name):
+        return torch.cat([c.field(name) for c in self.chunks])
+
+    @property
+    def vis_t(self):
+        return torch.cat([c.vis_t for c in self.chunks])
+
+    @property
+    def vis_t_minus(self):
+        if self.chunks[0].vis_t_minus is None:
+            return None
+        return torch.cat([c.vis_t_minus for c in self.chunks])
+
+    @vis_t_minus.setter
+    def vis_t_minus(self, t):
+        for (a, b), c in zip(self.bounds, self.chunks):
+            c.vis_t_minus = None if t is None else t.reshape(-1)[a:b].contiguous()
+
+    @property
+    def ebar(self):
+        """d loss / d e for all points, padded like a ResidualPlan's (seed of the entropy-net backward)."""
+        out = torch.zeros(((self.n + 127) // 128) * 128, dtype=torch.float32, device=self.net.device)
+        for (a, b), c in zip(self.bounds, self.chunks):
+            out[a:b] = c.ebar[:b - a]
+        return out
 
 
 class ValuePlan(PointPlan):
@@ -296,9 +353,18 @@ class PinnEngine:
         return self.flat[self.P + self.P1:]
 
     # ---- data ----
-    def set_collocation(self, x, y, weights=None, n_global=None):
+    def set_collocation(self, x, y, weights=None, n_global=None, chunk_points=None):
+        """chunk_points (or $NSFNET_CHUNK_POINTS): process the set in passes of that many points sharing
+        one activation workspace (ChunkedResidual); default: one pass, everything resident."""
+        import os
         self._graphs.clear()      # captured steps hold the old plan's pointers
-        self.plan_f = ResidualPlan(self.net, x, y, weights)
+        if chunk_points is None and os.environ.get("NSFNET_CHUNK_POINTS"):
+            chunk_points = int(os.environ["NSFNET_CHUNK_POINTS"])
+        n = int(np.asarray(x).size)
+        if chunk_points and n > int(chunk_points):
+            self.plan_f = ChunkedResidual(self.net, x, y, weights, chunk_points)
+        else:
+            self.plan_f = ResidualPlan(self.net, x, y, weights)
         self.n_f_global = int(n_global if n_global is not None else self.plan_f.n)
         if self.net_e is not None:
             self.plan_e = ValuePlan(self.net_e, x, y)
@@ -355,15 +421,29 @@ class PinnEngine:
         if self.net_e is not None:
             self.plan_e.forward(save=self.e_trainable)
             e = self.plan_e.pred[0]
-        f.forward(self.Re, e=e, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
-                  sums_out=sums[S_EQ:S_EQ + NLOSS])
         c = 2.0 * self.alpha_e / self.n_f_global
         coef_eq = (c, c, c, c * self.eq4_weight if self.net_e is not None else 0.0)
-        f.backward(self.Re, coef_eq, e=e, scale=self.scale, want_ebar=self.e_trainable)
-        if side is not None:
-            main.wait_stream(side)
-        plans = [f, b] if s is None else [f, b, s]
-        grad_reduce(self.net, plans, self.grads)
+        value_plans = [b] if s is None else [b, s]
+        if isinstance(f, ChunkedResidual):
+            # one pass per chunk through the shared workspace; gradients / sums accumulate
+            sums[S_EQ:S_EQ + NLOSS].zero_()
+            for k, ((lo, hi_), ck) in enumerate(zip(f.bounds, f.chunks)):
+                ek = None if e is None else e[lo:hi_]
+                ck.forward(self.Re, e=ek, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
+                           sums_out=f.tmp_sums)
+                sums[S_EQ:S_EQ + NLOSS] += f.tmp_sums
+                ck.backward(self.Re, coef_eq, e=ek, scale=self.scale, want_ebar=self.e_trainable)
+                grad_reduce(self.net, [ck], self.grads, accumulate=k > 0)
+            if side is not None:
+                main.wait_stream(side)
+            grad_reduce(self.net, value_plans, self.grads, accumulate=True)
+        else:
+            f.forward(self.Re, e=e, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
+                      sums_out=sums[S_EQ:S_EQ + NLOSS])
+            f.backward(self.Re, coef_eq, e=e, scale=self.scale, want_ebar=self.e_trainable)
+            if side is not None:
+                main.wait_stream(side)
+            grad_reduce(self.net, [f] + value_plans, self.grads)
         if self.net_e is not None:
             if self.e_trainable:
                 self.plan_e.backward(out_adj=f.ebar)

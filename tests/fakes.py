@@ -50,8 +50,9 @@ def _vec(a):
 
 
 class FakeResidualPlan:
-    def __init__(self, net, x, y, weights=None, with_backward=True):
+    def __init__(self, net, x, y, weights=None, with_backward=True, ws=None):
         self.net, self.x, self.y = net, _vec(x), _vec(y)
+        self.ws = ws if ws is not None else torch.zeros(1)
         self.n = self.x.numel()
         self.npad = (self.n + 31) // 32 * 32
         self.fields = torch.zeros(eng.FLD_COUNT, self.npad)
