@@ -109,6 +109,7 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
         f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * 32), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * 32);
         f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * 32), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * 32);
         f32x4 z0, z1, z2, z3;
+        float dbq[4], wq0[4], wq1[4], wq2[4], dxq[4], dyq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -147,23 +148,35 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
             }
             z0[e] = zq[0]; z1[e] = zq[1]; z2[e] = zq[2]; z3[e] = zq[3];
           }
-          // skinny gradients: sum over the 32 columns held by this half-wave
-          dbv = sum32(dbv);
-          if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
-          if (l == L - 1) {
-            wo0 = sum32(wo0); wo1 = sum32(wo1); wo2 = sum32(wo2);
-            if (col == 0) {
-              sgacc[sg_wout(HP, L) + o] += wo0;
-              sgacc[sg_wout(HP, L) + HP + o] += wo1;
-              sgacc[sg_wout(HP, L) + 2 * HP + o] += wo2;
-            }
-          }
-          if (l == 0) {
-            dwx = sum32(dwx); dwy = sum32(dwy);
-            if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
-          } else {
+          dbq[e] = dbv; wq0[e] = wo0; wq1[e] = wo1; wq2[e] = wo2; dxq[e] = dwx; dyq[e] = dwy;
+          if (l != 0) {
             float* Xo = X + o * 128 + col;
             Xo[0] = z0[e]; Xo[32] = z1[e]; Xo[64] = z2[e]; Xo[96] = z3[e];
+          }
+        }
+        // skinny gradients: the four features' sums over the 32 columns of this half-wave at once
+        // (reduce_util.h: transposing butterfly); lane col == e commits feature e
+        {
+          const int o = ob + 8 * g + 4 * h + (col & 3);
+          const float dbv = sum_cols4<32>(dbq[0], dbq[1], dbq[2], dbq[3], lane);
+          float w0 = 0.f, w1 = 0.f, w2 = 0.f, dx = 0.f, dy = 0.f;
+          if (l == L - 1) {
+            w0 = sum_cols4<32>(wq0[0], wq0[1], wq0[2], wq0[3], lane);
+            w1 = sum_cols4<32>(wq1[0], wq1[1], wq1[2], wq1[3], lane);
+            w2 = sum_cols4<32>(wq2[0], wq2[1], wq2[2], wq2[3], lane);
+          }
+          if (l == 0) {
+            dx = sum_cols4<32>(dxq[0], dxq[1], dxq[2], dxq[3], lane);
+            dy = sum_cols4<32>(dyq[0], dyq[1], dyq[2], dyq[3], lane);
+          }
+          if (col < 4) {
+            sgacc[sg_db(HP, l) + o] += dbv;
+            if (l == L - 1) {
+              sgacc[sg_wout(HP, L) + o] += w0;
+              sgacc[sg_wout(HP, L) + HP + o] += w1;
+              sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+            }
+            if (l == 0) { sgacc[sg_w0x(HP, L) + o] += dx; sgacc[sg_w0y(HP, L) + o] += dy; }
           }
         }
         if (l > 0) {
