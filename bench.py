@@ -215,14 +215,17 @@ def main():
         names = {"fp32": ("fwd_wide_kernel", "bwd_wide_kernel", "dw_wide_kernel") if wide else ("fwd_kernel", "bwd_kernel", "dw_kernel"),
                  "bf16x3": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel"),
                  "bf16": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel")}[prec]
+        if H > 256 and prec != "fp32":     # wide nets: bf16 sweeps (64 features per wave) + the fp32 dW kernel
+            names = ("fwd_bf16_wide_kernel", "bwd_bf16_wide_kernel", "dw_wide_kernel")
         kernels = dict(zip(names, (t_fwd, t_bwd, t_dw)))
         dom = max(kernels, key=kernels.get)
         achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[prec]
+        dom_prec = "fp32" if (dom.startswith("dw_wide") or prec == "fp32") else prec
+        peak = MFMA_PEAK_TFLOPS[dom_prec]
         traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid, n_launch) == (6, 256, 600, n_local) else None
         return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
-                    traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[prec],
-                    mfma_issue_frac=achieved * MFMA_PER_PRODUCT[prec] / peak,
+                    traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[dom_prec],
+                    mfma_issue_frac=achieved * MFMA_PER_PRODUCT[dom_prec] / peak,
                     kernel_ms={k: round(v, 4) for k, v in kernels.items()},
                     step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12,
                     forward_only_evals_per_s=n_launch / (t_fwd * 1e-3))

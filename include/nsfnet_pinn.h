@@ -40,7 +40,7 @@ int pinn_abi_version(void);
 /* ---- network description --------------------------------------------------
  * Replaces FCNet.__init__ (NSFnet/net.py:23-50): 2 inputs, `n_hidden_layers` tanh
  * layers of width `hidden`, `n_out` linear outputs (3 = u,v,p ; 1 = entropy residual e).
- * hidden <= 256 in this release. */
+ * hidden <= 512. */
 int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out);
 int pinn_net_destroy(pinn_net_t net);
 /* Arithmetic of the three MFMA kernel families (forward sweep, reverse sweep, weight-gradient

@@ -48,7 +48,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // different columns is bank-conflict free.  PPL = 32 (128-column tile) or 16 (64-column tile).
 template <int HP, int PPL = 32>
 struct XImg {
-  static constexpr int RSE = HP <= 32 ? 32 : HP <= 64 ? 64 : HP <= 128 ? 128 : 256;
+  static constexpr int RSE = HP <= 32 ? 32 : HP <= 64 ? 64 : HP <= 128 ? 128 : HP <= 256 ? 256 : 512;
   static constexpr int NCH = RSE / 8;                    // chunks per row
   static constexpr int R = RSE >= 128 ? 1 : 128 / RSE;   // rows per 256-byte bank row
   static constexpr int MASK = (NCH < 16 ? NCH : 16) - 1;

@@ -93,8 +93,9 @@ int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_
   if (!net) return fail(-22, "pinn_net_set_precision: null net%s");
   if (prec_fwd < 0 || prec_fwd > 2 || prec_bwd < 0 || prec_bwd > 2 || prec_dw < 0 || prec_dw > 2)
     return fail(-22, "pinn_net_set_precision: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16)%s");
-  if (net->HP > 256 && (prec_fwd || prec_bwd || prec_dw))
-    return fail(-22, "pinn_net_set_precision: the bf16 modes support hidden <= 256; wider nets run the fp32 MFMA path%s");
+  // hidden > 256: forward and reverse sweep have bf16 kernels (64 features per wave); the weight-gradient
+  // GEMM of wide nets stays on the fp32 MFMA kernel (same S / Z-bar layout), whatever was asked for.
+  if (net->HP > 256) prec_dw = 0;
   net->prec_fwd = prec_fwd; net->prec_bwd = prec_bwd; net->prec_dw = prec_dw;
   net->wide = pick_wide(net);
   return 0;
@@ -131,8 +132,9 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     return b < 1 ? 1 : b;
   };
   const int cols = wide ? 64 : 128;
-  const size_t lds_f = net->prec_fwd ? fwd_bf16_lds_bytes(HP, L, cols) : wide ? fwd_wide_lds_bytes(HP) : fwd_lds_bytes(HP);
-  const size_t lds_b = net->prec_bwd ? bwd_bf16_lds_bytes(HP, L, cols) : wide ? bwd_wide_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
+  const bool wbf = HP > 256;   // wide bf16 kernels
+  const size_t lds_f = net->prec_fwd ? (wbf ? fwd_bf16_wide_lds_bytes(HP, L) : fwd_bf16_lds_bytes(HP, L, cols)) : wide ? fwd_wide_lds_bytes(HP) : fwd_lds_bytes(HP);
+  const size_t lds_b = net->prec_bwd ? (wbf ? bwd_bf16_wide_lds_bytes(HP, L) : bwd_bf16_lds_bytes(HP, L, cols)) : wide ? bwd_wide_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
   const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : wide ? dw_wide_lds_bytes() : dw_lds_bytes(HP);
   if (lds_b > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
@@ -187,7 +189,8 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
   a.dbg = env_int("PINN_DBG", 0);
   const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream)
+  int rc = plan->net.prec_fwd ? (plan->net.HP > 256 ? launch_fwd_bf16_wide(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                                                     : launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream))
            : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
                               : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
@@ -226,7 +229,8 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   int rc = 0;
   if (phases & 1) {
     const int cols = plan->net.wide ? 64 : 128;
-    rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream)
+    rc = plan->net.prec_bwd ? (plan->net.HP > 256 ? launch_bwd_bf16_wide(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                                                     : launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream))
          : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
                             : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
@@ -262,7 +266,8 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
   const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_fwd ? launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream)
+  int rc = plan->net.prec_fwd ? (plan->net.HP > 256 ? launch_fwd_bf16_wide(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
+                                                     : launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream))
            : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
                               : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
@@ -285,7 +290,8 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
   const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_bwd ? launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream)
+  int rc = plan->net.prec_bwd ? (plan->net.HP > 256 ? launch_bwd_bf16_wide(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
+                                                     : launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream))
            : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
                               : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");

@@ -90,6 +90,11 @@ int launch_dw_bf16(int HP, int NS, int terms, int cols, const DwArgs& a, hipStre
 size_t fwd_bf16_lds_bytes(int HP, int L, int cols);
 size_t bwd_bf16_lds_bytes(int HP, int L, int cols);
 size_t dw_bf16_lds_bytes(int HP);
+// hidden > 256: 64-column tiles, two 32-feature blocks per wave (fwd_bf16_wide.hip / bwd_bf16_wide.hip)
+int launch_fwd_bf16_wide(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
+int launch_bwd_bf16_wide(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);
+size_t fwd_bf16_wide_lds_bytes(int HP, int L);
+size_t bwd_bf16_wide_lds_bytes(int HP, int L);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,

@@ -65,8 +65,9 @@ def test_argument_errors_are_reported(lib):
     h = ctypes.c_void_p()
     assert lib.pinn_net_create(3, 6, 600, ctypes.byref(h)) < 0
     assert b"hidden width" in lib.pinn_last_error()
-    assert lib.pinn_net_create(3, 8, 400, ctypes.byref(h)) == 0          # wide nets: fp32 path only
-    assert lib.pinn_net_set_precision(h, 1, 1, 1) < 0 and b"hidden <= 256" in lib.pinn_last_error()
+    assert lib.pinn_net_create(3, 8, 400, ctypes.byref(h)) == 0          # wide nets: bf16 sweeps, fp32 dW
+    assert lib.pinn_net_set_precision(h, 1, 1, 1) == 0
+    assert lib.pinn_net_set_precision(h, 3, 0, 0) < 0 and b"precision must be" in lib.pinn_last_error()
     assert lib.pinn_net_set_precision(h, 0, 0, 0) == 0
     lib.pinn_net_destroy(h)
     assert lib.pinn_net_create(4, 6, 64, ctypes.byref(h)) < 0

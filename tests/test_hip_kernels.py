@@ -228,6 +228,37 @@ def test_config5_shape_ev_8x400_with_4x40_entropy_net():
     assert _rel_l2(E.grads_e.cpu().numpy(), ge) < 1e-4
 
 
+@pytest.mark.parametrize("H,L", [(400, 8), (288, 3), (512, 2), (330, 4)])
+def test_wide_nets_bf16x3_sweeps(H, L):
+    """hidden > 256 in bf16x3 mode: fwd_bf16_wide / bwd_bf16_wide (two 32-feature blocks per wave; odd block
+    counts: 288 = 9, 330 -> 352 = 11) + the fp32 dW kernel, against the fp64 oracle at the bf16x3 bar."""
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    N, Re = 300, 2000.0
+    flat = _rand_params(3, L, H, seed=21)
+    rng = np.random.RandomState(9)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    w = (0.5 + rng.rand(N)).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, precision="bf16x3")
+    E.net.set_flat(torch.tensor(flat))
+    E.set_collocation(x, y, weights=w)
+    E.set_boundary(xb, yb, ub, vb)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), Re, w=w.astype(np.float64))
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    for k, name in enumerate(("eq1", "eq2", "eq3")):
+        assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < 5e-4, name
+    np.testing.assert_allclose(E.sums.cpu().numpy()[0:3], r["sums"], rtol=2e-4)
+    np.testing.assert_allclose(E.sums.cpu().numpy()[8:10], b["sums"], rtol=2e-4)
+    assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
+    lt = E.loss_terms()
+    ref_loss = 10.0 * sum(b["sums"]) / len(xb) + sum(r["sums"]) / N
+    assert abs(float(lt["loss"]) - ref_loss) < 1e-4 * ref_loss
+
+
 @pytest.mark.parametrize("H", [128, 256])
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_64_column_tile_kernels_at_narrow_widths(H, prec, monkeypatch):
