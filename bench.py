@@ -215,12 +215,12 @@ def main():
         names = {"fp32": ("fwd_wide_kernel", "bwd_wide_kernel", "dw_wide_kernel") if wide else ("fwd_kernel", "bwd_kernel", "dw_kernel"),
                  "bf16x3": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel"),
                  "bf16": ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel")}[prec]
-        if H > 256 and prec != "fp32":     # wide nets: bf16 sweeps (64 features per wave) + the fp32 dW kernel
-            names = ("fwd_bf16_wide_kernel", "bwd_bf16_wide_kernel", "dw_wide_kernel")
+        if H > 256 and prec != "fp32":     # wide nets: 64 features per wave, blocked dW
+            names = ("fwd_bf16_wide_kernel", "bwd_bf16_wide_kernel", "dw_bf16_wide_kernel")
         kernels = dict(zip(names, (t_fwd, t_bwd, t_dw)))
         dom = max(kernels, key=kernels.get)
         achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
-        dom_prec = "fp32" if (dom.startswith("dw_wide") or prec == "fp32") else prec
+        dom_prec = prec
         peak = MFMA_PEAK_TFLOPS[dom_prec]
         traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid, n_launch) == (6, 256, 600, n_local) else None
         return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,

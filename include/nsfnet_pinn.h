@@ -47,7 +47,7 @@ int pinn_net_destroy(pinn_net_t net);
  * GEMM): 0 = f32-input MFMA (bit-exact fp32 fmaf chains, default), 1 = bf16x3 (fp32 operands
  * split into bf16 hi+lo, three bf16 MFMAs per product, fp32 accumulate; ~2^-17 relative per
  * product), 2 = plain bf16 operands (fast mode, does NOT meet the 1e-4 loss-parity bar).
- * Call before pinn_net_prepare / pinn_plan_create. */
+ * All three modes exist for every supported width (hidden <= 512).  Call before pinn_net_prepare / pinn_plan_create. */
 int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_dw);
 int64_t pinn_net_num_params(pinn_net_t net);
 int64_t pinn_net_prep_floats(pinn_net_t net);

@@ -93,9 +93,7 @@ int pinn_net_set_precision(pinn_net_t net, int prec_fwd, int prec_bwd, int prec_
   if (!net) return fail(-22, "pinn_net_set_precision: null net%s");
   if (prec_fwd < 0 || prec_fwd > 2 || prec_bwd < 0 || prec_bwd > 2 || prec_dw < 0 || prec_dw > 2)
     return fail(-22, "pinn_net_set_precision: precision must be 0 (fp32), 1 (bf16x3) or 2 (bf16)%s");
-  // hidden > 256: forward and reverse sweep have bf16 kernels (64 features per wave); the weight-gradient
-  // GEMM of wide nets stays on the fp32 MFMA kernel (same S / Z-bar layout), whatever was asked for.
-  if (net->HP > 256) prec_dw = 0;
+  // hidden > 256: fwd_bf16_wide / bwd_bf16_wide (64 features per wave) and the blocked dw_bf16_wide
   net->prec_fwd = prec_fwd; net->prec_bwd = prec_bwd; net->prec_dw = prec_dw;
   net->wide = pick_wide(net);
   return 0;
@@ -135,7 +133,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   const bool wbf = HP > 256;   // wide bf16 kernels
   const size_t lds_f = net->prec_fwd ? (wbf ? fwd_bf16_wide_lds_bytes(HP, L) : fwd_bf16_lds_bytes(HP, L, cols)) : wide ? fwd_wide_lds_bytes(HP) : fwd_lds_bytes(HP);
   const size_t lds_b = net->prec_bwd ? (wbf ? bwd_bf16_wide_lds_bytes(HP, L) : bwd_bf16_lds_bytes(HP, L, cols)) : wide ? bwd_wide_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
-  const size_t lds_d = net->prec_dw ? dw_bf16_lds_bytes(HP) : wide ? dw_wide_lds_bytes() : dw_lds_bytes(HP);
+  const size_t lds_d = net->prec_dw ? (wbf ? dw_bf16_wide_lds_bytes() : dw_bf16_lds_bytes(HP)) : wide ? dw_wide_lds_bytes() : dw_lds_bytes(HP);
   if (lds_b > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
@@ -206,6 +204,8 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
+  if (plan->net.prec_dw && plan->net.HP > 256)
+    return launch_dw_bf16_wide(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s);
   if (plan->net.prec_dw)
     return launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), plan->net.wide ? 64 : 128, d, s);
   if (plan->net.wide) return launch_dw_wide(plan->net.HP, plan->streams, d, s);

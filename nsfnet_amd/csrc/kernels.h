@@ -93,6 +93,8 @@ size_t dw_bf16_lds_bytes(int HP);
 // hidden > 256: 64-column tiles, two 32-feature blocks per wave (fwd_bf16_wide.hip / bwd_bf16_wide.hip)
 int launch_fwd_bf16_wide(int HP, int NS, int terms, const FwdArgs& a, int grid, hipStream_t s);
 int launch_bwd_bf16_wide(int HP, int NS, int terms, const BwdArgs& a, int grid, hipStream_t s);
+int launch_dw_bf16_wide(int HP, int NS, int terms, const DwArgs& a, hipStream_t s);
+size_t dw_bf16_wide_lds_bytes();
 size_t fwd_bf16_wide_lds_bytes(int HP, int L);
 size_t bwd_bf16_wide_lds_bytes(int HP, int L);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
