@@ -134,7 +134,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   const size_t lds_f = net->prec_fwd ? (wbf ? fwd_bf16_wide_lds_bytes(HP, L) : fwd_bf16_lds_bytes(HP, L, cols)) : wide ? fwd_wide_lds_bytes(HP) : fwd_lds_bytes(HP);
   const size_t lds_b = net->prec_bwd ? (wbf ? bwd_bf16_wide_lds_bytes(HP, L) : bwd_bf16_lds_bytes(HP, L, cols)) : wide ? bwd_wide_lds_bytes(HP, L) : bwd_lds_bytes(HP, L);
   const size_t lds_d = net->prec_dw ? (wbf ? dw_bf16_wide_lds_bytes() : dw_bf16_lds_bytes(HP)) : wide ? dw_wide_lds_bytes() : dw_lds_bytes(HP);
-  if (lds_b > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
+  if (lds_b > 163840 || lds_f > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
   p->grid_b = cus * bpc(lds_b);
