@@ -259,6 +259,34 @@ def test_wide_nets_bf16x3_sweeps(H, L):
     assert abs(float(lt["loss"]) - ref_loss) < 1e-4 * ref_loss
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_wide_net_predict_and_fast_mode(prec):
+    """8x400: value-mode prediction (evaluate / test path) and the plain-bf16 fast mode on the wide kernels."""
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    L, H, N = 8, 400, 500
+    flat = _rand_params(3, L, H, seed=31)
+    rng = np.random.RandomState(10)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, 10000.0, alpha_b=10.0, alpha_e=1.0, precision=prec)
+    E.net.set_flat(torch.tensor(flat))
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    pred = torch.stack(E.predict(x, y)).cpu().numpy()          # [3][N]
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    out, _ = fr.forward1(P, x.astype(np.float64), y.astype(np.float64))
+    tol = 2e-5 if prec == "bf16x3" else 3e-2
+    assert np.abs(pred.T - out).max() < tol * max(1.0, np.abs(out).max())
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    r = fr.pde_loss_and_grad(P, x.astype(np.float64), y.astype(np.float64), 10000.0)
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    g = E.grads.cpu().numpy()
+    assert np.isfinite(g).all()
+    assert _rel_l2(g, r["grad"] + b["grad"]) < (1e-4 if prec == "bf16x3" else 5e-2)
+
+
 @pytest.mark.parametrize("H", [128, 256])
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 def test_64_column_tile_kernels_at_narrow_widths(H, prec, monkeypatch):
