@@ -28,7 +28,10 @@ struct DwImg {
 };
 
 // ds_read_b64_tr_b16 through the compiler builtin (hipcc tracks its lgkmcnt itself)
-__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+// (the address stays an LDS-space pointer end to end: a generic pointer would cost an address-space cast,
+// i.e. three VALU instructions, per read)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ u32x2 tr_read(const lds_u8* p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   return __builtin_bit_cast(u32x2, v);
@@ -61,8 +64,13 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  f32x4 zr[4], sr[4];
-  auto gload = [&](int ch) {
+  // Software pipeline: while the MFMAs of chunk ch run out of LDS buffer ch&1, the SAME wave converts chunk
+  // ch+1 (requested one whole iteration earlier, so its data has landed) to bf16 hi/lo and stores it into the
+  // other buffer - that VALU / ds_write work can sit in the MFMA shadow (4 VALU per MFMA are free on gfx950,
+  // and a partner wave's VALU does NOT overlap this wave's MFMAs: tests/micro/mfma_valu_*.hip) - and then
+  // requests chunk ch+2 into the registers it has just freed.
+  f32x4 zrA[4], srA[4];
+  auto gload = [&](int ch, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
     const int tile = t0 + ch / CPT, c = ch % CPT;
     const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + (size_t)og * PPL + 8 * c + p;
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + (size_t)og * PPL + 8 * c + p;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
       sr[s] = __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * PPL);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const f32x4 (&zr)[4], const f32x4 (&sr)[4]) {
     f32x4 av[4];
     if (NS == 4) {
 #pragma unroll
@@ -97,25 +105,17 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
       if (TERMS == 3) *reinterpret_cast<u32x2*>(row + 3 * DI::ARR) = lo;
     }
   };
-
-  if (nch > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
   // transposed-read lane geometry: 16-lane group gq = lane>>4 -> feature half fb, k half (== h)
   const int li = lane & 15, fb = (lane >> 4) & 1, q = li >> 2, pp = li & 3;
   const int lane_off = (8 * h + q) * DI::RSB + (16 * fb + 4 * pp) * 2;
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nch) gload(ch + 1);
-    const unsigned char* B0 = ldsb + (size_t)buf * 4 * DI::ARR + lane_off;
+  auto mfma_chunk = [&](int buf) {
+    const lds_u8* B0 = (const lds_u8*)ldsb + buf * 4 * DI::ARR + lane_off;
 #pragma unroll
     for (int ks = 0; ks < DI::CH / 16; ++ks) {
       u32x4 zh[TM], zl[TM], ah[TN], al[TN];
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
-        const unsigned char* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
+        const lds_u8* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
         u32x2 x0 = tr_read(pz), x1 = tr_read(pz + 4 * DI::RSB);
         zh[m][0] = x0[0]; zh[m][1] = x0[1]; zh[m][2] = x1[0]; zh[m][3] = x1[1];
         if (TERMS == 3) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
       }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const unsigned char* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
+        const lds_u8* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
         u32x2 x0 = tr_read(pa), x1 = tr_read(pa + 4 * DI::RSB);
         ah[n][0] = x0[0]; ah[n][1] = x0[1]; ah[n][2] = x1[0]; ah[n][3] = x1[1];
         if (TERMS == 3) {
@@ -144,9 +144,32 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
           acc[m][n] = mfma_bf16(zh[m], ah[n], acc[m][n]);
         }
     }
-    if (ch + 1 < nch) lstore(buf ^ 1);
+  };
+
+  if (nch > 0) {
+    gload(0, zrA, srA);
+    lstore(0, zrA, srA);
+    if (nch > 1) gload(1, zrA, srA);
+  }
+  __syncthreads();
+  // steady state: MFMAs of chunk ch and the conversion of chunk ch+1 in ONE basic block (no branches: the
+  // request for chunk ch+2 is clamped to the last chunk), with the interleave prescribed to the scheduler:
+  // per MFMA one transposed LDS read for a later MFMA and a few VALU / one ds_write of the conversion.
+  for (int ch = 0; ch + 1 < nch; ++ch) {
+    const int buf = ch & 1;
+    mfma_chunk(buf);
+    lstore(buf ^ 1, zrA, srA);
+    gload(ch + 2 < nch ? ch + 2 : nch - 1, zrA, srA);
+    constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1);
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // conversion VALU in its shadow
+    }
     __syncthreads();
   }
+  if (nch > 0) mfma_chunk((nch - 1) & 1);
+  __syncthreads();
   float* slab = a.slabs + ((size_t)(l - 1) * a.groups + g) * HP * HP;
 #pragma unroll
   for (int m = 0; m < TM; ++m)
