@@ -34,7 +34,7 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 // ~2e-7, far below the bf16x3 operand rounding); saturates correctly at +-inf.  The bare v_rcp_f32
 // matters: an IEEE 1/x costs 11 VALU instructions, a fifth of the whole chain-rule epilogue.
 __device__ __forceinline__ float fast_tanh(float z) {
-  float e = __expf(2.f * z);
+  float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);     // exp(2z) = 2^(2 z log2 e): one multiply
   return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 

@@ -105,9 +105,10 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
       float* Zl = a.Zb + ((size_t)tile * L + l) * act_block(HP);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-        f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * 32), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * 32);
-        f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * 32), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * 32);
+        const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * 32 + col);
+        const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
+        f32x4 s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * 32) + so), s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * 32) + so);
+        f32x4 s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * 32) + so), s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * 32) + so);
         f32x4 z0, z1, z2, z3;
         float dbq[4], wq0[4], wq1[4], wq2[4], dxq[4], dyq[4];
 #pragma unroll
@@ -180,9 +181,9 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
           }
         }
         if (l > 0) {
-          f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * 32 + col;
-          __builtin_nontemporal_store(z0, Zg + 0 * (HP / 4) * 32); __builtin_nontemporal_store(z1, Zg + 1 * (HP / 4) * 32);
-          __builtin_nontemporal_store(z2, Zg + 2 * (HP / 4) * 32); __builtin_nontemporal_store(z3, Zg + 3 * (HP / 4) * 32);
+          const f32x4* Z4 = reinterpret_cast<const f32x4*>(Zl);
+          __builtin_nontemporal_store(z0, pin_base(Z4 + 0 * (HP / 4) * 32) + so); __builtin_nontemporal_store(z1, pin_base(Z4 + 1 * (HP / 4) * 32) + so);
+          __builtin_nontemporal_store(z2, pin_base(Z4 + 2 * (HP / 4) * 32) + so); __builtin_nontemporal_store(z3, pin_base(Z4 + 3 * (HP / 4) * 32) + so);
         }
       }
       if (l == 0) break;

@@ -126,9 +126,13 @@ __global__ __launch_bounds__(HP * 2, 2) void bwd_bf16_kernel(BwdArgs a) {
 
       // residual mode: tanh adjoint of one register quad (features ob+8g+4h+e, column pp), all streams
       auto adj_quad = [&](int g, const f32x4& ga, const f32x4& gx, const f32x4& gy, const f32x4& gd) {
-        const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-        f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * PPL), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * PPL);
-        f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * PPL), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * PPL);
+        // plane bases pinned to scalar registers + one 32-bit lane offset: one VALU per address instead of a
+        // 64-bit add pair (every VALU instruction of the epilogue costs its full issue time)
+        const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
+        constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per plane
+        auto plane = [&](const float* base, int k) { return pin_base(reinterpret_cast<const f32x4*>(base) + k * PLQ); };
+        f32x4 s0 = __builtin_nontemporal_load(plane(Sl, 0) + so), s1 = __builtin_nontemporal_load(plane(Sl, 1) + so);
+        f32x4 s2 = __builtin_nontemporal_load(plane(Sl, 2) + so), s3 = __builtin_nontemporal_load(plane(Sl, 3) + so);
         f32x4 z0, z1, z2, z3;
         // branch-free chain for the four features (the layer-specific skinny-gradient terms follow below,
         // once per quad: a branch per element splits this into blocks the scheduler cannot pack)
@@ -199,9 +203,8 @@ __global__ __launch_bounds__(HP * 2, 2) void bwd_bf16_kernel(BwdArgs a) {
           split4(z3[0], z3[1], z3[2], z3[3], vh, vl);
           *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
           if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
-          f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-          __builtin_nontemporal_store(z0, Zg + 0 * (HP / 4) * PPL); __builtin_nontemporal_store(z1, Zg + 1 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(z2, Zg + 2 * (HP / 4) * PPL); __builtin_nontemporal_store(z3, Zg + 3 * (HP / 4) * PPL);
+          __builtin_nontemporal_store(z0, plane(Zl, 0) + so); __builtin_nontemporal_store(z1, plane(Zl, 1) + so);
+          __builtin_nontemporal_store(z2, plane(Zl, 2) + so); __builtin_nontemporal_store(z3, plane(Zl, 3) + so);
         }
       };
 

@@ -147,9 +147,10 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
 #pragma unroll
           for (int gq = 0; gq < 2; ++gq) {
             const int g = gq + 2 * hi;
-            const f32x4* Sg = reinterpret_cast<const f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-            f32x4 s0 = __builtin_nontemporal_load(Sg + 0 * (HP / 4) * PPL), s1 = __builtin_nontemporal_load(Sg + 1 * (HP / 4) * PPL);
-            f32x4 s2 = __builtin_nontemporal_load(Sg + 2 * (HP / 4) * PPL), s3 = __builtin_nontemporal_load(Sg + 3 * (HP / 4) * PPL);
+            const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
+            const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
+            f32x4 s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * PPL) + so), s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+            f32x4 s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * PPL) + so), s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * PPL) + so);
             f32x4 z0, z1, z2, z3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -218,9 +219,9 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
               split4(z3[0], z3[1], z3[2], z3[3], vh, vl);
               *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
               if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
-              f32x4* Zg = reinterpret_cast<f32x4*>(Zl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-              __builtin_nontemporal_store(z0, Zg + 0 * (HP / 4) * PPL); __builtin_nontemporal_store(z1, Zg + 1 * (HP / 4) * PPL);
-              __builtin_nontemporal_store(z2, Zg + 2 * (HP / 4) * PPL); __builtin_nontemporal_store(z3, Zg + 3 * (HP / 4) * PPL);
+              const f32x4* Z4 = reinterpret_cast<const f32x4*>(Zl);
+              __builtin_nontemporal_store(z0, pin_base(Z4 + 0 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z1, pin_base(Z4 + 1 * (HP / 4) * PPL) + so);
+              __builtin_nontemporal_store(z2, pin_base(Z4 + 2 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z3, pin_base(Z4 + 3 * (HP / 4) * PPL) + so);
             }
           }
         } else {

@@ -185,7 +185,6 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
-  a.dbg = env_int("PINN_DBG", 0);
   const int cols = plan->net.wide ? 64 : 128;
   int rc = plan->net.prec_fwd ? (plan->net.HP > 256 ? launch_fwd_bf16_wide(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
                                                      : launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream))

@@ -53,12 +53,13 @@ __global__ __launch_bounds__(HP * 2) void dw_kernel(DwArgs a) {
   f32x4 zr[4], sr[4];
   auto gload = [&](int ch) {
     const int tile = t0 + (ch >> 2), c = ch & 3;
-    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
-    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * act_block(HP)) + (size_t)og * 32 + 8 * c + p;
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * act_block(HP)) + 8 * c;
+    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * act_block(HP)) + 8 * c;
+    const unsigned lo_ = (unsigned)(og * 32 + p);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = __builtin_nontemporal_load(Zg + (size_t)s * (HP / 4) * 32);
-      sr[s] = __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * 32);
+      zr[s] = __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * 32) + lo_);
+      sr[s] = __builtin_nontemporal_load(pin_base(Sg + (size_t)s * (HP / 4) * 32) + lo_);
     }
   };
   auto lstore = [&](int buf) {

@@ -72,12 +72,14 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
   f32x4 zrA[4], srA[4];
   auto gload = [&](int ch, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
     const int tile = t0 + ch / CPT, c = ch % CPT;
-    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + (size_t)og * PPL + 8 * c + p;
-    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + (size_t)og * PPL + 8 * c + p;
+    // (tile, layer, plane, chunk) bases are uniform: pinned to scalar registers, one 32-bit lane offset
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
+    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + 8 * c;
+    const unsigned lo_ = (unsigned)(og * PPL + p);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = __builtin_nontemporal_load(Zg + (size_t)s * (HP / 4) * PPL);
-      sr[s] = __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * PPL);
+      zr[s] = __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + lo_);
+      sr[s] = __builtin_nontemporal_load(pin_base(Sg + (size_t)s * (HP / 4) * PPL) + lo_);
     }
   };
   auto lstore = [&](int buf, const f32x4 (&zr)[4], const f32x4 (&sr)[4]) {

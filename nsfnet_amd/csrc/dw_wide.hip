@@ -34,12 +34,13 @@ __global__ __launch_bounds__(512) void dw_wide_kernel(DwArgs a, int HP) {
   f32x4 zr[4], sr[4];
   auto gload = [&](int ch) {
     const int tile = t0 + ch / (PPL / 8), c = ch % (PPL / 8);
-    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * blk) + (size_t)ogz * PPL + 8 * c + p;
-    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * blk) + (size_t)oga * PPL + 8 * c + p;
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * blk) + 8 * c;
+    const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * blk) + 8 * c;
+    const unsigned loz = (unsigned)(ogz * PPL + p), loa = (unsigned)(oga * PPL + p);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      zr[s] = vz ? __builtin_nontemporal_load(Zg + (size_t)s * (HP / 4) * PPL) : f32x4{0.f, 0.f, 0.f, 0.f};
-      sr[s] = va ? __builtin_nontemporal_load(Sg + (size_t)s * (HP / 4) * PPL) : f32x4{0.f, 0.f, 0.f, 0.f};
+      zr[s] = vz ? __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + loz) : f32x4{0.f, 0.f, 0.f, 0.f};
+      sr[s] = va ? __builtin_nontemporal_load(pin_base(Sg + (size_t)s * (HP / 4) * PPL) + loa) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&](int buf) {

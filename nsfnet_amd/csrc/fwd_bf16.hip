@@ -104,7 +104,6 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
                       const f32x4& s0, const f32x4& s1, const f32x4& s2, const f32x4& s3) {
         const int off = XI::chunk_off(pp, (ob >> 3) + g) + 8 * h;
         u32x2 vh, vl;
-        if (!(a.dbg & 4)) {
         split4(a0[0], a0[1], a0[2], a0[3], vh, vl);
         *reinterpret_cast<u32x2*>(Xb + 0 * XI::PLANE * 2 + off) = vh;
         if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 0 * XI::PLANE * 2 + off) = vl;
@@ -117,20 +116,17 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
         split4(a3[0], a3[1], a3[2], a3[3], vh, vl);
         *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
         if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
-        } else { asm volatile("" :: "v"(a0[0] + a1[1] + a2[2] + a3[3])); }
-        if (Sl && !(a.dbg & 2)) {
-          f32x4* Sg = reinterpret_cast<f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-#ifndef PINN_NO_NT   // streamed once: keep the spill out of L2's way (measured -3 % on the kernel)
-          __builtin_nontemporal_store(s0, Sg + 0 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(s1, Sg + 1 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
-          __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
-#else
-          Sg[0 * (HP / 4) * PPL] = s0;
-          Sg[1 * (HP / 4) * PPL] = s1;
-          Sg[2 * (HP / 4) * PPL] = s2;
-          Sg[3 * (HP / 4) * PPL] = s3;
-#endif
+        if (Sl) {
+          // uniform plane bases (scalar registers) + ONE 32-bit lane offset: the stores then take the
+          // saddr + voffset form instead of a 64-bit VALU address per plane
+          const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
+          constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per plane
+          const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
+          // streamed once: nontemporal keeps the spill out of L2's way (measured -3 % on the kernel)
+          __builtin_nontemporal_store(s0, pin_base(S4 + 0 * PLQ) + so);
+          __builtin_nontemporal_store(s1, pin_base(S4 + 1 * PLQ) + so);
+          __builtin_nontemporal_store(s2, pin_base(S4 + 2 * PLQ) + so);
+          __builtin_nontemporal_store(s3, pin_base(S4 + 3 * PLQ) + so);
         }
       };
       auto chain = [&](float z, float zx, float zy, float zd, int e, f32x4& a0, f32x4& a1, f32x4& a2, f32x4& a3,
@@ -222,10 +218,9 @@ __global__ __launch_bounds__(HP * 2, (COLS == 64 && HP == 256) ? 4 : 2) void fwd
             if (TERMS == 3) bo[j] = *reinterpret_cast<const u32x4*>(Xl + XI::HALF * 2 + j * TSTR + off0);
           }
         }
-        if (!(a.dbg & 1))
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          if (s + PRE < KS && !(a.dbg & 8)) {     // stream the weight fragments PRE k-steps ahead
+          if (s + PRE < KS) {     // stream the weight fragments PRE k-steps ahead
             wh[(s + PRE) % RING] = wf[(s + PRE) * 64];
             if (TERMS == 3) wl[(s + PRE) % RING] = wf[(size_t)(HP * HP / 8) + (s + PRE) * 64];
           }

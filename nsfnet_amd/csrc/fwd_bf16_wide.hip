@@ -132,11 +132,12 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void fwd_bf16_wide_kernel
             *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
             if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
             if (Sl) {
-              f32x4* Sg = reinterpret_cast<f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-              __builtin_nontemporal_store(s0, Sg + 0 * (HP / 4) * PPL);
-              __builtin_nontemporal_store(s1, Sg + 1 * (HP / 4) * PPL);
-              __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
-              __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
+              const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
+              const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
+              __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * PPL) + so);
+              __builtin_nontemporal_store(s1, pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+              __builtin_nontemporal_store(s2, pin_base(S4 + 2 * (HP / 4) * PPL) + so);
+              __builtin_nontemporal_store(s3, pin_base(S4 + 3 * (HP / 4) * PPL) + so);
             }
           }
         } else {

@@ -91,11 +91,12 @@ __global__ __launch_bounds__(HP * 2) void fwd_wide_kernel(FwdArgs a) {
             s0[e] = t; s1[e] = zx; s2[e] = zy; s3[e] = zd;
           }
           if (Sl) {
-            f32x4* Sg = reinterpret_cast<f32x4*>(Sl) + (size_t)((ob >> 2) + 2 * g + h) * PPL + pp;
-            __builtin_nontemporal_store(s0, Sg + 0 * (HP / 4) * PPL);
-            __builtin_nontemporal_store(s1, Sg + 1 * (HP / 4) * PPL);
-            __builtin_nontemporal_store(s2, Sg + 2 * (HP / 4) * PPL);
-            __builtin_nontemporal_store(s3, Sg + 3 * (HP / 4) * PPL);
+            const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
+            const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
+            __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * PPL) + so);
+            __builtin_nontemporal_store(s1, pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+            __builtin_nontemporal_store(s2, pin_base(S4 + 2 * (HP / 4) * PPL) + so);
+            __builtin_nontemporal_store(s3, pin_base(S4 + 3 * (HP / 4) * PPL) + so);
           }
         }
       } else {

@@ -7,6 +7,17 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef __HIPCC__
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+// A uniform (tile, layer, plane) base pinned to scalar registers: lane addresses then cost ONE VALU (base +
+// 32-bit offset) instead of a 64-bit add pair per plane - the epilogues pay full issue time for every VALU.
+__device__ __forceinline__ gf32x4* pin_base(const void* q) {
+  const unsigned long long b = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return (gf32x4*)(((unsigned long long)hi << 32) | lo);
+}
+#endif
+
 // Field planes written by the residual forward and read by the backward
 // (plane stride = padded point count).
 enum { FLD_U = 0, FLD_V, FLD_UX, FLD_UY, FLD_VX, FLD_VY, FLD_EQ1, FLD_EQ2, FLD_EQ3, FLD_EQ4, FLD_P, FLD_COUNT };
@@ -33,7 +44,6 @@ struct FwdArgs {
   float coef[3];         // oadj_c = coef[c] * (pred_c - tgt_c)
   float* partials;       // [grid][PINN_NLOSS]
   int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
-  int dbg;               // timing-only ablation bits (PINN_DBG): 1 skip MFMA loop, 2 skip S stores, 4 skip LDS restage
 };
 
 struct BwdArgs {
