@@ -171,13 +171,13 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
             dy = sum_cols4<32>(dyq[0], dyq[1], dyq[2], dyq[3], lane);
           }
           if (col < 4) {
-            sgacc[sg_db(HP, l) + o] += dbv;
+            lds_add(&sgacc[sg_db(HP, l) + o], dbv);
             if (l == L - 1) {
-              sgacc[sg_wout(HP, L) + o] += w0;
-              sgacc[sg_wout(HP, L) + HP + o] += w1;
-              sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+              lds_add(&sgacc[sg_wout(HP, L) + o], w0);
+              lds_add(&sgacc[sg_wout(HP, L) + HP + o], w1);
+              lds_add(&sgacc[sg_wout(HP, L) + 2 * HP + o], w2);
             }
-            if (l == 0) { sgacc[sg_w0x(HP, L) + o] += dx; sgacc[sg_w0y(HP, L) + o] += dy; }
+            if (l == 0) { lds_add(&sgacc[sg_w0x(HP, L) + o], dx); lds_add(&sgacc[sg_w0y(HP, L) + o], dy); }
           }
         }
         if (l > 0) {

@@ -195,13 +195,13 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
                 dy = sum_cols4<PPL>(dwyv[0], dwyv[1], dwyv[2], dwyv[3], lane);
               }
               if (pp < 4) {
-                sgacc[sg_db(HP, l) + o] += dbv;
+                lds_add(&sgacc[sg_db(HP, l) + o], dbv);
                 if (l == L - 1) {
-                  sgacc[sg_wout(HP, L) + o] += w0;
-                  sgacc[sg_wout(HP, L) + HP + o] += w1;
-                  sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+                  lds_add(&sgacc[sg_wout(HP, L) + o], w0);
+                  lds_add(&sgacc[sg_wout(HP, L) + HP + o], w1);
+                  lds_add(&sgacc[sg_wout(HP, L) + 2 * HP + o], w2);
                 }
-                if (l == 0) { sgacc[sg_w0x(HP, L) + o] += dx; sgacc[sg_w0y(HP, L) + o] += dy; }
+                if (l == 0) { lds_add(&sgacc[sg_w0x(HP, L) + o], dx); lds_add(&sgacc[sg_w0y(HP, L) + o], dy); }
               }
             }
             if (l > 0) {
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
                   const int o = ob + 8 * g + 4 * h + e;
                   float w0 = sum_cols<32>(oc[0][j] * t4[e]), w1 = sum_cols<32>(oc[1][j] * t4[e]), w2 = sum_cols<32>(oc[2][j] * t4[e]);
                   if (col == 0) {
-                    sgacc[sg_wout(HP, L) + o] += w0;
-                    sgacc[sg_wout(HP, L) + HP + o] += w1;
-                    sgacc[sg_wout(HP, L) + 2 * HP + o] += w2;
+                    lds_add(&sgacc[sg_wout(HP, L) + o], w0);
+                    lds_add(&sgacc[sg_wout(HP, L) + HP + o], w1);
+                    lds_add(&sgacc[sg_wout(HP, L) + 2 * HP + o], w2);
                   }
                 }
               }
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
 #pragma unroll
               for (int j = 0; j < NTL; ++j) { dbv += zj[j][e]; dwx += zj[j][e] * px[j]; dwy += zj[j][e] * py[j]; }
               dbv = sum_cols<32>(dbv);
-              if (col == 0) sgacc[sg_db(HP, l) + o] += dbv;
+              if (col == 0) lds_add(&sgacc[sg_db(HP, l) + o], dbv);
               if (l == 0) {
                 dwx = sum_cols<32>(dwx); dwy = sum_cols<32>(dwy);
-                if (col == 0) { sgacc[sg_w0x(HP, L) + o] += dwx; sgacc[sg_w0y(HP, L) + o] += dwy; }
+                if (col == 0) { lds_add(&sgacc[sg_w0x(HP, L) + o], dwx); lds_add(&sgacc[sg_w0y(HP, L) + o], dwy); }
               }
             }
           }

@@ -51,3 +51,10 @@ template <int W>
 __device__ __forceinline__ float sum_cols4(float v0, float v1, float v2, float v3, int lane) {
   return sum_cols4_t(v0, v1, v2, v3, lane, W == 32);
 }
+
+// sgacc[i] += v as ONE ds_add_f32 (no returned value, no read-modify-write round trip through registers and
+// its lgkmcnt wait).  Every accumulator slot is only ever updated by the wave that owns the feature, in program
+// order, so the sums stay deterministic.
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
