@@ -13,7 +13,8 @@ struct DI {                                      // staging image of one 256-fea
   static constexpr int ARR = CH * RSB;           // bytes per array per buffer; arrays: Z hi, Z lo, A hi, A lo
   static constexpr size_t BYTES = (size_t)2 * 4 * ARR;
 };
-__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+typedef __attribute__((address_space(3))) unsigned char lds_u8;   // LDS-space pointer end to end (no generic casts)
+__device__ __forceinline__ u32x2 tr_read(const lds_u8* p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   return __builtin_bit_cast(u32x2, v);
@@ -89,24 +90,17 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
     }
   };
 
-  if (nch > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
   // transposed-read lane geometry: 16-lane group gq = lane>>4 -> feature half fb, k half (== h)
   const int li = lane & 15, fb = (lane >> 4) & 1, q = li >> 2, pp = li & 3;
   const int lane_off = (8 * h + q) * DI::RSB + (16 * fb + 4 * pp) * 2;
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nch) gload(ch + 1);
-    const unsigned char* B0 = ldsb + (size_t)buf * 4 * DI::ARR + lane_off;
+  auto mfma_chunk = [&](int buf) {
+    const lds_u8* B0 = (const lds_u8*)ldsb + buf * 4 * DI::ARR + lane_off;
 #pragma unroll
     for (int ks = 0; ks < DI::CH / 16; ++ks) {
       u32x4 zh[TM], zl[TM], ah[TN], al[TN];
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
-        const unsigned char* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
+        const lds_u8* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
         u32x2 x0 = tr_read(pz), x1 = tr_read(pz + 4 * DI::RSB);
         zh[m][0] = x0[0]; zh[m][1] = x0[1]; zh[m][2] = x1[0]; zh[m][3] = x1[1];
         if (TERMS == 3) {
@@ -116,7 +110,7 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
       }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
-        const unsigned char* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
+        const lds_u8* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
         u32x2 x0 = tr_read(pa), x1 = tr_read(pa + 4 * DI::RSB);
         ah[n][0] = x0[0]; ah[n][1] = x0[1]; ah[n][2] = x1[0]; ah[n][3] = x1[1];
         if (TERMS == 3) {
@@ -136,9 +130,30 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
             acc[m][n] = mfma_bf16(zh[m], ah[n], acc[m][n]);
           }
     }
-    if (ch + 1 < nch) lstore(buf ^ 1);
+  };
+  // software pipeline as in dw_bf16.hip: the conversion of chunk ch+1 (requested one iteration earlier) and the
+  // request for chunk ch+2 sit in the same basic block as the MFMAs of chunk ch
+  if (nch > 0) {
+    gload(0);
+    lstore(0);
+    if (nch > 1) gload(1);
+  }
+  __syncthreads();
+  for (int ch = 0; ch + 1 < nch; ++ch) {
+    const int buf = ch & 1;
+    mfma_chunk(buf);
+    lstore(buf ^ 1);
+    gload(ch + 2 < nch ? ch + 2 : nch - 1);
+    constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1);
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // conversion VALU in its shadow
+    }
     __syncthreads();
   }
+  if (nch > 0) mfma_chunk((nch - 1) & 1);
+  __syncthreads();
   float* slab = a.slabs + ((size_t)(l - 1) * a.groups + g) * HP * HP;
 #pragma unroll
   for (int m = 0; m < TM; ++m)
