@@ -35,6 +35,7 @@ enum {
 #define PINN_NLOSS 8
 
 const char* pinn_last_error(void);
+/* 2 = this header (1 + pinn_adam_step_dev; bf16 modes for every width up to 512). */
 int pinn_abi_version(void);
 
 /* ---- network description --------------------------------------------------

@@ -74,7 +74,7 @@ static int env_int(const char* name, int dflt) {
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err; }
-int pinn_abi_version(void) { return 1; }
+int pinn_abi_version(void) { return 2; }   // 2: + pinn_adam_step_dev, hidden <= 512 in every precision mode
 
 int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out) {
   if (!out) return fail(-22, "pinn_net_create: null out%s");

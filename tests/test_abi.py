@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.pinn_abi_version() == 1
+    assert lib.pinn_abi_version() == 2
     h = ctypes.c_void_p()
     assert lib.pinn_net_create(3, 6, 256, ctypes.byref(h)) == 0
     assert lib.pinn_net_num_params(h) == fr.param_count(2, 3, 6, 256) == 330499
