@@ -37,6 +37,12 @@ PMC_TRAFFIC_BYTES = {   # profiles/r01_final_bf16x3_pmc_summary.txt, profiles/r0
     ("bf16x3", "fwd_bf16_kernel"): 8.882e9, ("bf16x3", "bwd_bf16_kernel"): 1.626e10, ("bf16x3", "dw_bf16_kernel"): 1.481e10,
     ("fp32", "fwd_wide_kernel"): 8.885e9, ("fp32", "bwd_wide_kernel"): 1.627e10, ("fp32", "dw_wide_kernel"): 1.481e10,
 }
+# Matrix-pipe utilisation of the same launches, SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), from the
+# same PMC summaries (the chip holds 1.6-1.9 GHz under this load, so this is not frac x mfma_per_product).
+PMC_MFMA_BUSY = {
+    ("bf16x3", "fwd_bf16_kernel"): 0.52, ("bf16x3", "bwd_bf16_kernel"): 0.38, ("bf16x3", "dw_bf16_kernel"): 0.57,
+    ("fp32", "fwd_wide_kernel"): 0.80, ("fp32", "bwd_wide_kernel"): 0.65, ("fp32", "dw_wide_kernel"): 0.83,
+}
 
 
 def weight_count(L, H, n_out=3):
@@ -222,10 +228,12 @@ def main():
         achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
         dom_prec = prec
         peak = MFMA_PEAK_TFLOPS[dom_prec]
-        traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if (L, H, args.grid, n_launch) == (6, 256, 600, n_local) else None
+        default_cfg = (L, H, args.grid, n_launch) == (6, 256, 600, n_local)
+        traffic = PMC_TRAFFIC_BYTES.get((prec, dom)) if default_cfg else None
+        pipe_busy = PMC_MFMA_BUSY.get((prec, dom)) if default_cfg else None
         return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                     traffic=traffic, mfma_per_product=MFMA_PER_PRODUCT[dom_prec],
-                    mfma_issue_frac=achieved * MFMA_PER_PRODUCT[dom_prec] / peak,
+                    mfma_issue_frac=achieved * MFMA_PER_PRODUCT[dom_prec] / peak, matrix_pipe_busy_pmc=pipe_busy,
                     kernel_ms={k: round(v, 4) for k, v in kernels.items()},
                     step_tflops=24.0 * pw * n_local / (ms_step * 1e-3) / 1e12,
                     forward_only_evals_per_s=n_launch / (t_fwd * 1e-3))
