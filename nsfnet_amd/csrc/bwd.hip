@@ -8,6 +8,7 @@
 // the weight-gradient GEMM (dw.hip), and the skinny gradients (all biases, layer 0,
 // output layer) are reduced in-kernel.
 #include "kernels.h"
+#include "point_stage.h"
 #include "reduce_util.h"
 
 template <int HP, int NS>
@@ -29,59 +30,9 @@ __global__ __launch_bounds__(HP * 2) void bwd_kernel(BwdArgs a) {
   __syncthreads();
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    // ---------------- output adjoints per column ----------------
+    // ---------------- output adjoints per column (point_stage.h) ----------------
     float px[4], py[4];
-    if (NS == 4) {
-      const int ptc = tile * 32 + col;
-      px[0] = ptc < a.n ? a.x[ptc] : 0.f;
-      py[0] = ptc < a.n ? a.y[ptc] : 0.f;
-      if (tid < 32) {
-        const int pt = tile * 32 + tid;
-        const bool m = pt < a.n;
-        const float* f = a.fld + pt;
-        float u = f[FLD_U * (size_t)npad], v = f[FLD_V * (size_t)npad];
-        float ux = f[FLD_UX * (size_t)npad], uy = f[FLD_UY * (size_t)npad];
-        float vx = f[FLD_VX * (size_t)npad], vy = f[FLD_VY * (size_t)npad];
-        float eq1 = f[FLD_EQ1 * (size_t)npad], eq2 = f[FLD_EQ2 * (size_t)npad];
-        float eq3 = f[FLD_EQ3 * (size_t)npad], eq4 = f[FLD_EQ4 * (size_t)npad];
-        float ww = m ? (a.w ? a.w[pt] : 1.f) : 0.f;
-        float g1 = a.coef_eq[0] * ww * eq1, g2 = a.coef_eq[1] * ww * eq2, g3 = a.coef_eq[2] * ww * eq3;
-        float g4 = a.e ? a.coef_eq[3] * ww * eq4 : 0.f;
-        float r1 = g1 + g4 * (u - 0.5f), r2 = g2 + g4 * (v - 0.5f), r3 = g3;
-        float nu = a.inv_re + ((a.vis_used && m) ? a.vis_used[pt] : 0.f);
-        const float sc = a.scale, sc2 = a.scale * a.scale;
-        float au = r1 * ux + r2 * vx + g4 * eq1;
-        float av = r1 * uy + r2 * vy + g4 * eq2;
-        oadjL[0 * 128 + 0 + tid] = au;
-        oadjL[0 * 128 + 32 + tid] = (r1 * u + r3) * sc;
-        oadjL[0 * 128 + 64 + tid] = (r1 * v) * sc;
-        oadjL[0 * 128 + 96 + tid] = -nu * r1 * sc2;
-        oadjL[1 * 128 + 0 + tid] = av;
-        oadjL[1 * 128 + 32 + tid] = (r2 * u) * sc;
-        oadjL[1 * 128 + 64 + tid] = (r2 * v + r3) * sc;
-        oadjL[1 * 128 + 96 + tid] = -nu * r2 * sc2;
-        oadjL[2 * 128 + 0 + tid] = 0.f;
-        oadjL[2 * 128 + 32 + tid] = r1 * sc;
-        oadjL[2 * 128 + 64 + tid] = r2 * sc;
-        oadjL[2 * 128 + 96 + tid] = 0.f;
-        if (a.ebar && m) a.ebar[pt] = -g4;
-        dbo[0] += au; dbo[1] += av;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int pt = tile * 128 + 32 * j + col;
-        px[j] = pt < a.n ? a.x[pt] : 0.f;
-        py[j] = pt < a.n ? a.y[pt] : 0.f;
-      }
-      for (int idx = tid; idx < 3 * 128; idx += NT) {
-        int c = idx >> 7, cc = idx & 127;
-        int pt = tile * 128 + cc;
-        float v = (c < a.n_out && pt < a.n) ? a.oadj[(size_t)c * npad + pt] : 0.f;
-        oadjL[idx] = v;
-        if (c == 0) dbo[0] += v; else if (c == 1) dbo[1] += v; else dbo[2] += v;
-      }
-    }
+    output_adjoint_stage<32, 128, NS, NT, 4>(a, tile, tid, col, col, npad, oadjL, dbo, px, py);
     __syncthreads();
     // ---------------- adjoint of the last hidden layer's activations (3 -> HP, rank-3) ----------------
     f32x16 acc[4];

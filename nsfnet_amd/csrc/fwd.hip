@@ -13,6 +13,7 @@
 // the four 32-column blocks (= the four streams of 32 points), so the tanh chain rule
 // that mixes the four streams of one (point, feature) is lane-local on the accumulators.
 #include "kernels.h"
+#include "point_stage.h"
 
 template <int HP, int NS>
 __global__ __launch_bounds__(HP * 2) void fwd_kernel(FwdArgs a) {
@@ -153,63 +154,9 @@ __global__ __launch_bounds__(HP * 2) void fwd_kernel(FwdArgs a) {
       outv[c * 128 + cc] = s;
     }
     __syncthreads();
-    // ---------------- per-point stage ----------------
-    if (NS == 4) {
-      if (tid < 32) {
-        const int pt = tile * 32 + tid;
-        const bool m = pt < a.n;
-        const float sc = a.scale, sc2 = a.scale * a.scale;
-        float u = outv[tid], ux = outv[32 + tid] * sc, uy = outv[64 + tid] * sc, ud = outv[96 + tid] * sc2;
-        float v = outv[128 + tid], vx = outv[160 + tid] * sc, vy = outv[192 + tid] * sc, vd = outv[224 + tid] * sc2;
-        float p = outv[256 + tid], pxx = outv[288 + tid] * sc, pyy = outv[320 + tid] * sc;
-        float vt = 0.f;
-        float ev = (a.e && m) ? a.e[pt] : 0.f;
-        if (a.vtm && m) {                       // ev-NSFnet/pinn_solver.py:327-334
-          vt = fminf(a.vis_t0, a.vtm[pt]);
-          a.vtm[pt] = a.alpha_evm * fabsf(ev);
-        }
-        if (a.vis_used && m) a.vis_used[pt] = vt;
-        float nu = a.inv_re + vt;
-        float eq1 = (u * ux + v * uy) + pxx - nu * ud;
-        float eq2 = (u * vx + v * vy) + pyy - nu * vd;
-        float eq3 = ux + vy;
-        float eq4 = a.e ? (eq1 * (u - 0.5f) + eq2 * (v - 0.5f)) - ev : 0.f;
-        float* f = a.fld + pt;
-        f[FLD_U * (size_t)npad] = u; f[FLD_V * (size_t)npad] = v;
-        f[FLD_UX * (size_t)npad] = ux; f[FLD_UY * (size_t)npad] = uy;
-        f[FLD_VX * (size_t)npad] = vx; f[FLD_VY * (size_t)npad] = vy;
-        f[FLD_EQ1 * (size_t)npad] = eq1; f[FLD_EQ2 * (size_t)npad] = eq2;
-        f[FLD_EQ3 * (size_t)npad] = eq3; f[FLD_EQ4 * (size_t)npad] = eq4;
-        f[FLD_P * (size_t)npad] = p;
-        if (m) {
-          float ww = a.w ? a.w[pt] : 1.f;
-          lsum[0] += ww * eq1 * eq1; lsum[1] += ww * eq2 * eq2;
-          lsum[2] += ww * eq3 * eq3; lsum[3] += ww * eq4 * eq4;
-        }
-      }
-    } else {
-      for (int idx = tid; idx < 128; idx += NT) {
-        const int pt = tile * 128 + idx;
-        const bool m = pt < a.n;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          if (c >= a.n_out) break;
-          float pv = outv[c * 128 + idx];
-          if (a.pred[c] && m) a.pred[c][pt] = pv;
-          float adj = 0.f;
-          if (a.tgt[c] && m) {
-            float t = a.tgt[c][pt];
-            if (t == t && fabsf(t) <= 3.0e38f) {   // finite target (NaN pressure = masked, ev:405-410)
-              float d = pv - t;
-              lsum[c] += d * d;
-              lsum[3] += (c == 2) ? 1.f : 0.f;     // count of valid pressure targets
-              adj = a.coef[c] * d;
-            }
-          }
-          if (a.oadj) a.oadj[(size_t)c * npad + pt] = adj;
-        }
-      }
-    }
+    // ---------------- per-point stage (point_stage.h) ----------------
+    if (NS == 4) residual_point_stage<32, 128>(a, outv, tile, tid, npad, lsum);
+    else value_point_stage<128, NT>(a, outv, tile, tid, npad, lsum);
     __syncthreads();
   }
   // ---------------- block reduction of the loss partial sums (fixed order) ----------------

@@ -11,6 +11,7 @@
 // (hi, lo) B fragments from the LDS image for 12 MFMAs - the same ratio as the 128-column kernel.
 // If HP/32 is odd the last wave owns one block.
 #include "kernels.h"
+#include "point_stage.h"
 #include "bf16_util.h"
 #include <type_traits>
 
@@ -277,64 +278,9 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void fwd_bf16_wide_kernel
       outv[c3 * COLS + cc] = s;
     }
     __syncthreads();
-    // ---------------- per-point stage (identical to fwd_bf16.hip) ----------------
-    if (NS == 4) {
-      if (tid < PPL) {
-        const int pt = tile * PPL + tid;
-        const bool m = pt < a.n;
-        const float sc = a.scale, sc2 = a.scale * a.scale;
-        float u = outv[tid], ux = outv[PPL + tid] * sc, uy = outv[2 * PPL + tid] * sc, ud = outv[3 * PPL + tid] * sc2;
-        float v = outv[COLS + tid], vx = outv[COLS + PPL + tid] * sc, vy = outv[COLS + 2 * PPL + tid] * sc,
-              vd = outv[COLS + 3 * PPL + tid] * sc2;
-        float p = outv[2 * COLS + tid], pxx = outv[2 * COLS + PPL + tid] * sc, pyy = outv[2 * COLS + 2 * PPL + tid] * sc;
-        float vt = 0.f;
-        float ev = (a.e && m) ? a.e[pt] : 0.f;
-        if (a.vtm && m) {
-          vt = fminf(a.vis_t0, a.vtm[pt]);
-          a.vtm[pt] = a.alpha_evm * fabsf(ev);
-        }
-        if (a.vis_used && m) a.vis_used[pt] = vt;
-        float nu = a.inv_re + vt;
-        float eq1 = (u * ux + v * uy) + pxx - nu * ud;
-        float eq2 = (u * vx + v * vy) + pyy - nu * vd;
-        float eq3 = ux + vy;
-        float eq4 = a.e ? (eq1 * (u - 0.5f) + eq2 * (v - 0.5f)) - ev : 0.f;
-        float* f = a.fld + pt;
-        f[FLD_U * (size_t)npad] = u; f[FLD_V * (size_t)npad] = v;
-        f[FLD_UX * (size_t)npad] = ux; f[FLD_UY * (size_t)npad] = uy;
-        f[FLD_VX * (size_t)npad] = vx; f[FLD_VY * (size_t)npad] = vy;
-        f[FLD_EQ1 * (size_t)npad] = eq1; f[FLD_EQ2 * (size_t)npad] = eq2;
-        f[FLD_EQ3 * (size_t)npad] = eq3; f[FLD_EQ4 * (size_t)npad] = eq4;
-        f[FLD_P * (size_t)npad] = p;
-        if (m) {
-          float ww = a.w ? a.w[pt] : 1.f;
-          lsum[0] += ww * eq1 * eq1; lsum[1] += ww * eq2 * eq2;
-          lsum[2] += ww * eq3 * eq3; lsum[3] += ww * eq4 * eq4;
-        }
-      }
-    } else {
-      for (int idx = tid; idx < COLS; idx += NT) {
-        const int pt = tile * COLS + idx;
-        const bool m = pt < a.n;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          if (c >= a.n_out) break;
-          float pv = outv[c * COLS + idx];
-          if (a.pred[c] && m) a.pred[c][pt] = pv;
-          float adj = 0.f;
-          if (a.tgt[c] && m) {
-            float t = a.tgt[c][pt];
-            if (t == t && fabsf(t) <= 3.0e38f) {
-              float d = pv - t;
-              lsum[c] += d * d;
-              lsum[3] += (c == 2) ? 1.f : 0.f;
-              adj = a.coef[c] * d;
-            }
-          }
-          if (a.oadj) a.oadj[(size_t)c * npad + pt] = adj;
-        }
-      }
-    }
+    // ---------------- per-point stage (point_stage.h) ----------------
+    if (NS == 4) residual_point_stage<PPL, COLS>(a, outv, tile, tid, npad, lsum);
+    else value_point_stage<COLS, NT>(a, outv, tile, tid, npad, lsum);
     __syncthreads();
   }
   float* red = reinterpret_cast<float*>(ldsb);

@@ -9,6 +9,7 @@
 // every lane owns all four streams of 8 of the 16 accumulator rows.  With up to 16 waves per
 // workgroup a wave has 128 VGPRs, so the weight slice streams through a small register ring.
 #include "kernels.h"
+#include "point_stage.h"
 
 template <int HP, int NS>
 __global__ __launch_bounds__(HP * 2) void fwd_wide_kernel(FwdArgs a) {
@@ -165,62 +166,9 @@ __global__ __launch_bounds__(HP * 2) void fwd_wide_kernel(FwdArgs a) {
       outv[c3 * COLS + cc] = s;
     }
     __syncthreads();
-    if (NS == 4) {
-      if (tid < PPL) {
-        const int pt = tile * PPL + tid;
-        const bool m = pt < a.n;
-        const float sc = a.scale, sc2 = a.scale * a.scale;
-        float u = outv[tid], ux = outv[16 + tid] * sc, uy = outv[32 + tid] * sc, ud = outv[48 + tid] * sc2;
-        float v = outv[64 + tid], vx = outv[80 + tid] * sc, vy = outv[96 + tid] * sc, vd = outv[112 + tid] * sc2;
-        float p = outv[128 + tid], pxx = outv[144 + tid] * sc, pyy = outv[160 + tid] * sc;
-        float vt = 0.f;
-        float ev = (a.e && m) ? a.e[pt] : 0.f;
-        if (a.vtm && m) {
-          vt = fminf(a.vis_t0, a.vtm[pt]);
-          a.vtm[pt] = a.alpha_evm * fabsf(ev);
-        }
-        if (a.vis_used && m) a.vis_used[pt] = vt;
-        float nu = a.inv_re + vt;
-        float eq1 = (u * ux + v * uy) + pxx - nu * ud;
-        float eq2 = (u * vx + v * vy) + pyy - nu * vd;
-        float eq3 = ux + vy;
-        float eq4 = a.e ? (eq1 * (u - 0.5f) + eq2 * (v - 0.5f)) - ev : 0.f;
-        float* f = a.fld + pt;
-        f[FLD_U * (size_t)npad] = u; f[FLD_V * (size_t)npad] = v;
-        f[FLD_UX * (size_t)npad] = ux; f[FLD_UY * (size_t)npad] = uy;
-        f[FLD_VX * (size_t)npad] = vx; f[FLD_VY * (size_t)npad] = vy;
-        f[FLD_EQ1 * (size_t)npad] = eq1; f[FLD_EQ2 * (size_t)npad] = eq2;
-        f[FLD_EQ3 * (size_t)npad] = eq3; f[FLD_EQ4 * (size_t)npad] = eq4;
-        f[FLD_P * (size_t)npad] = p;
-        if (m) {
-          float ww = a.w ? a.w[pt] : 1.f;
-          lsum[0] += ww * eq1 * eq1; lsum[1] += ww * eq2 * eq2;
-          lsum[2] += ww * eq3 * eq3; lsum[3] += ww * eq4 * eq4;
-        }
-      }
-    } else {
-      for (int idx = tid; idx < COLS; idx += NT) {
-        const int pt = tile * COLS + idx;
-        const bool m = pt < a.n;
-#pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) {
-          if (c3 >= a.n_out) break;
-          float pv = outv[c3 * COLS + idx];
-          if (a.pred[c3] && m) a.pred[c3][pt] = pv;
-          float adj = 0.f;
-          if (a.tgt[c3] && m) {
-            float t = a.tgt[c3][pt];
-            if (t == t && fabsf(t) <= 3.0e38f) {
-              float d = pv - t;
-              lsum[c3] += d * d;
-              lsum[3] += (c3 == 2) ? 1.f : 0.f;
-              adj = a.coef[c3] * d;
-            }
-          }
-          if (a.oadj) a.oadj[(size_t)c3 * npad + pt] = adj;
-        }
-      }
-    }
+    // ---------------- per-point stage (point_stage.h) ----------------
+    if (NS == 4) residual_point_stage<PPL, COLS>(a, outv, tile, tid, npad, lsum);
+    else value_point_stage<COLS, NT>(a, outv, tile, tid, npad, lsum);
     __syncthreads();
   }
   float* red = lds;
