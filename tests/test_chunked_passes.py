@@ -106,3 +106,34 @@ def test_chunked_kernels_match_single_pass(prec):
     np.testing.assert_allclose(b["eq2"], a["eq2"], rtol=0, atol=1e-5 * np.abs(a["eq2"]).max())
     np.testing.assert_allclose(b["vt"], a["vt"], rtol=1e-6)
     np.testing.assert_allclose(b["p"], a["p"], rtol=0, atol=1e-6)
+
+
+def test_precision_spec_parsing(monkeypatch):
+    from nsfnet_amd import engine as eng
+    monkeypatch.delenv("NSFNET_PRECISION", raising=False)
+    assert eng.resolve_precision() == ("fp32", "fp32", "fp32")
+    assert eng.resolve_precision("bf16x3") == ("bf16x3",) * 3
+    assert eng.resolve_precision("bf16x3,fp32,bf16") == ("bf16x3", "fp32", "bf16")
+    monkeypatch.setenv("NSFNET_PRECISION", "bf16")
+    assert eng.resolve_precision() == ("bf16",) * 3
+    with pytest.raises(ValueError):
+        eng.resolve_precision("fp16")
+    with pytest.raises(ValueError):
+        eng.resolve_precision("fp32,bf16")
+
+
+def test_chunk_bounds_are_tile_aligned(monkeypatch):
+    """Chunk boundaries sit on multiples of 128 points (every tile size divides it), chunks cover the set once,
+    and a chunk size below the alignment is rounded up to it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fakes
+    fakes.install(monkeypatch)
+    from nsfnet_amd import engine as eng
+    net = eng.DeviceNet(3, 2, 8, torch.device("cpu"))
+    x = np.linspace(0, 1, 1000); y = x[::-1].copy()
+    for chunk, sizes in ((300, [256, 256, 256, 232]), (50, [128] * 7 + [104]), (4096, [1000])):
+        c = eng.ChunkedResidual(net, x, y, None, chunk)
+        assert [b - a for a, b in c.bounds] == sizes
+        assert c.bounds[0][0] == 0 and c.bounds[-1][1] == 1000
+        assert all(a % 128 == 0 for a, _ in c.bounds)
+        assert c.n == 1000 and len({id(p.ws) for p in c.chunks}) == 1
