@@ -41,7 +41,7 @@ PMC_TRAFFIC_BYTES = {   # profiles/r01_final_bf16x3_pmc_summary.txt, profiles/r0
 # same PMC summaries (the chip holds 1.6-1.9 GHz under this load, so this is not frac x mfma_per_product).
 PMC_MFMA_BUSY = {
     ("bf16x3", "fwd_bf16_kernel"): 0.52, ("bf16x3", "bwd_bf16_kernel"): 0.38, ("bf16x3", "dw_bf16_kernel"): 0.57,
-    ("fp32", "fwd_wide_kernel"): 0.80, ("fp32", "bwd_wide_kernel"): 0.65, ("fp32", "dw_wide_kernel"): 0.83,
+    ("fp32", "fwd_wide_kernel"): 0.80, ("fp32", "bwd_wide_kernel"): 0.66, ("fp32", "dw_wide_kernel"): 0.83,
 }
 
 
