@@ -317,12 +317,10 @@ size_t bwd_bf16_wide_lds_bytes(int HP, int L) {
 template <int HP, int NS, int TERMS>
 static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
   size_t lds = bwd_bf16_wide_lds_bytes(HP, a.L);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_bf16_wide_kernel<HP, NS, TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_lds = lds;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((bwd_bf16_wide_kernel<HP, NS, TERMS>), dim3(grid), dim3(((HP / 32 + 1) / 2) * 64), lds, s, a);
   hipError_t e = hipGetLastError();

@@ -210,12 +210,10 @@ template <int HP, int NS>
 static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
   size_t lds = bwd_wide_lds_bytes(HP, a.L);
   if (lds > 163840) return -1001;
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_wide_kernel<HP, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_lds = lds;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((bwd_wide_kernel<HP, NS>), dim3(grid), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

@@ -52,16 +52,14 @@ struct pinn_plan_s {
   size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
 };
 
+// compute units of the CURRENT device (queried per plan: no cached value, a process may drive several devices)
 static int num_cus() {
-  static int cached = 0;
-  if (cached) return cached;
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cached = prop.multiProcessorCount;
-  else
-    cached = 256;   // MI355X
-  return cached;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+    return n;
+  (void)hipGetLastError();
+  return 256;   // MI355X (also what a device-less host sizes workspaces for)
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -70,6 +68,32 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }  // (declared above pick_wide)
+
+// kernel-family dispatch (precision x tile geometry), shared by the launches and by pinn_plan_create's
+// configure pass (args.configure = 1: set the dynamic-LDS attribute of exactly the kernel a launch would pick)
+static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s) {
+  const pinn_net_s& n = plan->net;
+  const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (n.prec_fwd)
+    return n.HP > 256 ? launch_fwd_bf16_wide(n.HP, NS, terms_of(n.prec_fwd), a, plan->grid_f, s)
+                      : launch_fwd_bf16(n.HP, NS, terms_of(n.prec_fwd), cols, a, plan->grid_f, s);
+  return n.wide ? launch_fwd_wide(n.HP, NS, a, plan->grid_f, s) : launch_fwd(n.HP, NS, a, plan->grid_f, s);
+}
+static int dispatch_bwd(const pinn_plan_s* plan, const BwdArgs& a, hipStream_t s) {
+  const pinn_net_s& n = plan->net;
+  const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (n.prec_bwd)
+    return n.HP > 256 ? launch_bwd_bf16_wide(n.HP, NS, terms_of(n.prec_bwd), a, plan->grid_b, s)
+                      : launch_bwd_bf16(n.HP, NS, terms_of(n.prec_bwd), cols, a, plan->grid_b, s);
+  return n.wide ? launch_bwd_wide(n.HP, NS, a, plan->grid_b, s) : launch_bwd(n.HP, NS, a, plan->grid_b, s);
+}
+static int dispatch_dw(const pinn_plan_s* plan, const DwArgs& d, hipStream_t s) {
+  const pinn_net_s& n = plan->net;
+  if (n.prec_dw && n.HP > 256) return launch_dw_bf16_wide(n.HP, plan->streams, terms_of(n.prec_dw), d, s);
+  if (n.prec_dw) return launch_dw_bf16(n.HP, plan->streams, terms_of(n.prec_dw), n.wide ? 64 : 128, d, s);
+  if (n.wide) return launch_dw_wide(n.HP, plan->streams, d, s);
+  return launch_dw(n.HP, plan->streams, d, s);
+}
 
 extern "C" {
 
@@ -157,6 +181,20 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   p->off_S = off;        off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
   p->off_Zb = off;       off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
   p->bytes_all = off;
+  // Raise the dynamic-LDS limit of the kernels this plan will launch, on the CURRENT device.  It is per-device
+  // state of the HIP runtime and idempotent; doing it here, per plan, keeps the launch path free of cached
+  // "already configured" flags (no global mutable state; a process may drive several devices and threads).
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { ndev = 0; (void)hipGetLastError(); }
+  if (ndev > 0) {     // (a host without a device can still size workspaces; it cannot launch anyway)
+    FwdArgs fa; memset(&fa, 0, sizeof(fa)); fa.L = L; fa.configure = 1;
+    BwdArgs ba; memset(&ba, 0, sizeof(ba)); ba.L = L; ba.configure = 1;
+    DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1;
+    int rc = dispatch_fwd(p, fa, nullptr);
+    if (!rc) rc = dispatch_bwd(p, ba, nullptr);
+    if (!rc) rc = dispatch_dw(p, da, nullptr);
+    if (rc) { delete p; return hipfail(rc, "pinn_plan_create(kernel attributes)"); }
+  }
   *out = p;
   return 0;
 }
@@ -185,11 +223,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
-  const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_fwd ? (plan->net.HP > 256 ? launch_fwd_bf16_wide(plan->net.HP, 4, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                                                     : launch_fwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream))
-           : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream)
-                              : launch_fwd(plan->net.HP, 4, a, plan->grid_f, (hipStream_t)stream);
+  int rc = dispatch_fwd(plan, a, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -203,12 +237,8 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
-  if (plan->net.prec_dw && plan->net.HP > 256)
-    return launch_dw_bf16_wide(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), d, s);
-  if (plan->net.prec_dw)
-    return launch_dw_bf16(plan->net.HP, plan->streams, terms_of(plan->net.prec_dw), plan->net.wide ? 64 : 128, d, s);
-  if (plan->net.wide) return launch_dw_wide(plan->net.HP, plan->streams, d, s);
-  return launch_dw(plan->net.HP, plan->streams, d, s);
+  d.configure = 0;
+  return dispatch_dw(plan, d, s);
 }
 
 int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
@@ -227,11 +257,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {
-    const int cols = plan->net.wide ? 64 : 128;
-    rc = plan->net.prec_bwd ? (plan->net.HP > 256 ? launch_bwd_bf16_wide(plan->net.HP, 4, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                                                     : launch_bwd_bf16(plan->net.HP, 4, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream))
-         : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream)
-                            : launch_bwd(plan->net.HP, 4, a, plan->grid_b, (hipStream_t)stream);
+    rc = dispatch_bwd(plan, a, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
   }
   if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
@@ -264,11 +290,7 @@ int pinn_value_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = save ? WS(plan, off_oadj) : nullptr;
   a.scale = 1.f;
   a.partials = WS(plan, off_partials);
-  const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_fwd ? (plan->net.HP > 256 ? launch_fwd_bf16_wide(plan->net.HP, 1, terms_of(plan->net.prec_fwd), a, plan->grid_f, (hipStream_t)stream)
-                                                     : launch_fwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_fwd), cols, a, plan->grid_f, (hipStream_t)stream))
-           : plan->net.wide   ? launch_fwd_wide(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream)
-                              : launch_fwd(plan->net.HP, 1, a, plan->grid_f, (hipStream_t)stream);
+  int rc = dispatch_fwd(plan, a, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_forward");
   if (loss_sums) {
     rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
@@ -288,11 +310,7 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.oadj = out_adj ? out_adj : WS(plan, off_oadj);
   a.scale = 1.f;
   a.sg = WS(plan, off_sg);
-  const int cols = plan->net.wide ? 64 : 128;
-  int rc = plan->net.prec_bwd ? (plan->net.HP > 256 ? launch_bwd_bf16_wide(plan->net.HP, 1, terms_of(plan->net.prec_bwd), a, plan->grid_b, (hipStream_t)stream)
-                                                     : launch_bwd_bf16(plan->net.HP, 1, terms_of(plan->net.prec_bwd), cols, a, plan->grid_b, (hipStream_t)stream))
-           : plan->net.wide   ? launch_bwd_wide(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream)
-                              : launch_bwd(plan->net.HP, 1, a, plan->grid_b, (hipStream_t)stream);
+  int rc = dispatch_bwd(plan, a, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");
   rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;

@@ -131,12 +131,10 @@ int dw_threads(int HP) { return HP * 2; }
 template <int HP, int NS>
 static int launch_one(const DwArgs& a, hipStream_t s) {
   size_t lds = dw_lds_bytes(HP);
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_kernel<HP, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((dw_kernel<HP, NS>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

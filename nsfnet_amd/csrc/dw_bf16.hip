@@ -199,12 +199,10 @@ size_t dw_bf16_lds_bytes(int HP) {
 template <int HP, int NS, int TERMS, int PPL>
 static int launch_one(const DwArgs& a, hipStream_t s) {
   size_t lds = lds_bytes_t<HP>();
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS, PPL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS, PPL>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

@@ -174,12 +174,10 @@ size_t dw_bf16_wide_lds_bytes() { return DI::BYTES; }
 
 template <int NS, int TERMS>
 static int launch_one(int HP, const DwArgs& a, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_wide_kernel<NS, TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DI::BYTES);
-    if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   const int nblk = (HP / 32 + 7) / 8;
   hipLaunchKernelGGL((dw_bf16_wide_kernel<NS, TERMS>), dim3(a.groups, a.L - 1, nblk * nblk), dim3(512), DI::BYTES, s, a, HP);

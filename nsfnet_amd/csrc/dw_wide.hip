@@ -115,15 +115,13 @@ int launch_dw_wide(int HP, int NS, const DwArgs& a, hipStream_t s) {
   if (a.L <= 1 || a.groups <= 0) return 0;
   const int T = HP / 32, nblk = (T + 7) / 8;
   size_t lds = dw_wide_lds_bytes();
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wide_kernel<4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wide_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   dim3 grid(a.groups, a.L - 1, nblk * nblk);
   if (NS == 4) hipLaunchKernelGGL((dw_wide_kernel<4>), grid, dim3(512), lds, s, a, HP);

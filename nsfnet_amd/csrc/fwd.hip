@@ -178,12 +178,10 @@ size_t fwd_lds_bytes(int HP) { return ((size_t)HP * 128 + (size_t)(HP / 32) * 4 
 template <int HP, int NS>
 static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   size_t lds = fwd_lds_bytes(HP);
-  static bool attr_done = false;
-  if (!attr_done) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_kernel<HP, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_done = true;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_kernel<HP, NS>), dim3(grid), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

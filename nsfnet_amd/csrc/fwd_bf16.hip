@@ -326,12 +326,10 @@ size_t fwd_bf16_lds_bytes(int HP, int L, int cols) {
 template <int HP, int NS, int TERMS, int COLS>
 static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   size_t lds = lds_bytes_t<HP, COLS>(a.L);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bf16_kernel<HP, NS, TERMS, COLS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_lds = lds;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_bf16_kernel<HP, NS, TERMS, COLS>), dim3(grid), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();

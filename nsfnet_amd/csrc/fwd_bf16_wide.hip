@@ -310,12 +310,10 @@ int fwd_bf16_wide_threads(int HP) { return ((HP / 32 + 1) / 2) * 64; }
 template <int HP, int NS, int TERMS>
 static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   size_t lds = lds_bytes_t<HP>(a.L);
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bf16_wide_kernel<HP, NS, TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return -(int)e;
-    attr_lds = lds;
+    return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_bf16_wide_kernel<HP, NS, TERMS>), dim3(grid), dim3(((HP / 32 + 1) / 2) * 64), lds, s, a);
   hipError_t e = hipGetLastError();

@@ -44,6 +44,7 @@ struct FwdArgs {
   float coef[3];         // oadj_c = coef[c] * (pred_c - tgt_c)
   float* partials;       // [grid][PINN_NLOSS]
   int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
+  int configure;         // 1: do not launch, only raise the kernel's dynamic-LDS limit (pinn_plan_create)
 };
 
 struct BwdArgs {
@@ -60,12 +61,14 @@ struct BwdArgs {
   // value mode
   const float* oadj;     // [4][npad]
   float* sg;             // [grid][sg_total]
+  int configure;         // see FwdArgs
 };
 
 struct DwArgs {
   const float* S; const float* Zb;
   int ntiles, L, groups;
   float* slabs;          // [(L-1)][groups][HP*HP]
+  int configure;         // see FwdArgs
 };
 
 struct ReduceSrc { const float* slabs; int groups; const float* sg; int nwg; };

@@ -7,10 +7,10 @@
 // ordered copies (layout.h).  Wf: lane (i = lane&31, h = lane>>5) of wave w holds
 // W[32w+i][2ks+h] for ks = 0..HP/2-1, four ks per 16-byte load.  WTf: same with W^T.
 // ---------------------------------------------------------------------------
+// fp32 -> bf16, round to nearest even, through the hardware conversion (v_cvt_pk_bf16_f32): unlike the integer
+// (u + 0x7FFF + lsb) >> 16 idiom it keeps a NaN a NaN, so a NaN weight still poisons the loss in the bf16 modes
 __device__ __forceinline__ unsigned short f2bf_rne(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return __builtin_bit_cast(unsigned short, (__bf16)x);
 }
 
 // bf16 fragment element `pos` (0 .. HP*HP-1) of the hi (lo_part = 0) or lo (lo_part = 1) array:

@@ -337,6 +337,7 @@ class PinnEngine:
         import os
         self._overlap = os.environ.get("NSFNET_OVERLAP_BC", "1") not in ("0", "", "false")
         self.n_f_global = self.n_b_global = self.n_s_global = 0
+        self._n_p_local, self._n_p_valid, self._sup_stale = 0, None, False
         self.eq4_weight = 0.1
 
     # ---- views into the exchange buffer ----
@@ -376,25 +377,51 @@ class PinnEngine:
         self.n_b_global = int(n_global if n_global is not None else self.plan_b.n)
 
     def set_supervised(self, x, y, u, v, p=None, n_global=None):
-        if x is None:
-            self.plan_s, self.n_s_global = None, 0
-            self.sums[S_SUP:S_SUP + NLOSS].zero_()
-            return
+        """Supervised samples of THIS rank (ev-NSFnet/pinn_solver.py:202-251).  A rank's share may be
+        empty (np.array_split with fewer samples than ranks, :219-221; the reference then skips the
+        branch on that rank, :400): it contributes zero sums and no gradient but still takes part in
+        the step's all-reduce and divides by the global counts."""
         self._graphs.clear()      # captured steps hold the old plan's pointers
+        self._n_p_valid = None
+        self.sums[S_SUP:S_SUP + NLOSS].zero_()
+        self._sup_stale = False
+        if x is None:
+            self.plan_s, self.n_s_global, self._n_p_local = None, 0, 0
+            return
+        n_local = int(np.asarray(x).size)
+        self.n_s_global = int(n_global if n_global is not None else n_local)
+        if n_local == 0:
+            self.plan_s, self._n_p_local = None, 0
+            return
         self.plan_s = ValuePlan(self.net, x, y, targets=[u, v, p])
-        self.n_s_global = int(n_global if n_global is not None else self.plan_s.n)
+        self._n_p_local = 0 if p is None else int(np.isfinite(np.asarray(p, dtype=np.float64)).sum())
 
     def init_vis_t(self):
         """vis_t_minus = alpha_evm*|e(x_f)|   (ev-NSFnet/pinn_solver.py:138-140)"""
         self.plan_e.forward(save=False)
-        self.plan_f.vis_t_minus = (self.alpha_evm * self.plan_e.pred[0].abs()).contiguous()
+        fresh = (self.alpha_evm * self.plan_e.pred[0].abs()).contiguous()
+        cur = self.plan_f.vis_t_minus
+        if cur is not None and not isinstance(self.plan_f, ChunkedResidual) and cur.shape == fresh.shape:
+            cur.copy_(fresh)          # in place: a captured hipGraph keeps reading / writing this allocation
+        else:
+            self._graphs.clear()
+            self.plan_f.vis_t_minus = fresh
 
     # ---- one loss + gradient evaluation ----
     def loss_and_grad(self):
         f, b = self.plan_f, self.plan_b
         sums = self.sums
-        s = self.plan_s if (self.plan_s is not None and self.alpha_s != 0.0) else None
-        n_p = self._n_p_valid_global() if s is not None else 0
+        sup_on = self.n_s_global > 0 and self.alpha_s != 0.0
+        s = self.plan_s if sup_on else None             # None also on a rank whose supervised share is empty
+        n_p = self._n_p_valid_global() if sup_on else 0
+        if s is None and self._sup_stale:
+            # the supervised block is all-reduced in place with everything else: what an earlier step left
+            # there (this rank's own sums, or - on a rank with an empty share - the global sums) would be
+            # added again, and multiplied by world_size, every step
+            sums[S_SUP:S_SUP + NLOSS].zero_()
+            self._sup_stale = False
+        if sup_on:
+            self._sup_stale = True
         # The value-mode chains (boundary / supervised points: a few thousand points, latency-bound
         # kernels) are independent of the collocation chain until the gradient assembly: they run on a
         # second HIP stream beside it.
@@ -462,8 +489,7 @@ class PinnEngine:
 
     def _n_p_valid_global(self):
         if getattr(self, "_n_p_valid", None) is None:
-            t = self.plan_s.targets[2]
-            n = 0 if t is None else int(torch.isfinite(t).sum().item())
+            n = int(self._n_p_local)
             if self.world_size > 1:
                 tt = torch.tensor([n], dtype=torch.int64, device=self.device)
                 torch.distributed.all_reduce(tt, group=self.pg)
@@ -479,7 +505,7 @@ class PinnEngine:
         loss_b = (s[S_BC] + s[S_BC + 1]) / self.n_b_global
         out = dict(loss_eq1=eq[0], loss_eq2=eq[1], loss_eq3=eq[2], loss_eq4=eq[3], loss_e=loss_e, loss_b=loss_b)
         loss_s = torch.zeros((), device=self.device)
-        if self.plan_s is not None and self.alpha_s != 0.0:
+        if self.n_s_global > 0 and self.alpha_s != 0.0:
             n_p = self._n_p_valid_global()
             loss_s = (s[S_SUP] + s[S_SUP + 1]) / self.n_s_global + (s[S_SUP + 2] / n_p if n_p > 0 else 0.0)
         out["loss_s"] = loss_s

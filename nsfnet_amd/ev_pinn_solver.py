@@ -125,6 +125,10 @@ class PysicsInformedNeuralNetwork:
         """Contiguous blocks, last rank takes the remainder (:144-147, :165-168)."""
         w = self.world_size if self.is_distributed else 1
         r = self.rank if self.is_distributed else 0
+        if total < w:
+            # the reference would hand ranks 0..w-2 an empty block and divide by zero in their means; the
+            # count is global, so every rank raises here together instead of one rank leaving a collective
+            raise ValueError("%d points cannot be sharded over %d ranks" % (total, w))
         per = total // w
         lo = r * per
         hi = lo + per if r < w - 1 else total
@@ -202,8 +206,7 @@ class PysicsInformedNeuralNetwork:
         to_t = lambda a: None if a is None else torch.as_tensor(a).reshape(-1, 1).to(self.device)
         self.x_s, self.y_s, self.u_s, self.v_s, self.p_s = (to_t(a) for a in (xs, ys, us, vs, ps))
         self._p_mask = None if ps is None else torch.isfinite(self.p_s)
-        self.engine._n_p_valid = None
-        self.engine.set_supervised(xs, ys, us, vs, ps, n_global=total)
+        self.engine.set_supervised(xs, ys, us, vs, ps, n_global=total)    # an empty local share is allowed (:400)
         self.supervision_has_data = self.supervision_total_points > 0
         self.supervision_enabled = self.supervision_has_data and self.alpha_s != 0.0
         self.engine.alpha_s = float(self.alpha_s) if self.supervision_enabled else 0.0
@@ -276,15 +279,9 @@ class PysicsInformedNeuralNetwork:
         """Reference loop :440-487 incl. its schedule: the entropy net trains for exactly one
         step in every 10 000 and Adam is re-created (moments reset) at every stage start and at
         steps k*10000 and k*10000+1."""
-        if not hasattr(self, 'cumulative_start_time'):
-            self.cumulative_start_time = time.time()
-        self._epoch_start_wall = time.time()
-        self._last_log_time = self._epoch_start_wall
-        self._last_log_epoch = 0
+        self._last_log_time, self._last_log_epoch = time.time(), 0
         if not hasattr(self, 'log_interval'):
             self.log_interval = 100
-        if not hasattr(self, 'progress_bar_width'):
-            self.progress_bar_width = 30
         self.freeze_evm_net(0)
         fused = getattr(loss_func, "__func__", None) is PysicsInformedNeuralNetwork.fwd_computing_loss_2d
         for epoch_id in range(num_epoch):
@@ -330,93 +327,25 @@ class PysicsInformedNeuralNetwork:
 
     # ---------------------------------------------------------------- logging
     def print_log(self, loss, losses, epoch_id, num_epoch):
-        """Rank-0 progress block with the reference's fields (:513-650), incl. its throughput
-        definition interval_it/s * (N_f_local + N_b_local) (:581-591)."""
+        """Rank-0 progress line.  Kept from the reference's block (:513-650) only what defines a number
+        someone compares: throughput = steps/s since the last log x local (collocation + boundary) points
+        (:581-591) and Re_eff = 1 / (1/Re + mean vis_t) (:566-568)."""
         now = time.time()
-        for name, val in (('_epoch_start_wall', now), ('cumulative_start_time', now), ('_last_log_time', now),
-                          ('_last_log_epoch', 0)):
-            if not hasattr(self, name):
-                setattr(self, name, val)
-        stage_elapsed = now - self._epoch_start_wall
-        total_elapsed = now - self.cumulative_start_time
-        avg_it_s = (epoch_id + 1) / stage_elapsed if stage_elapsed > 0 else 0.0
-        interval_epochs = max(epoch_id - self._last_log_epoch, 1)
-        interval_time = now - self._last_log_time
-        interval_it_s = interval_epochs / interval_time if interval_time > 0 else 0.0
-        remain = num_epoch - (epoch_id + 1)
-        eta_sec = remain / avg_it_s if avg_it_s > 0 else float('inf')
+        steps = max(epoch_id - getattr(self, '_last_log_epoch', 0), 1)
+        dt = now - getattr(self, '_last_log_time', now)
+        rate = steps / dt if dt > 0 else 0.0
+        pts = sum(t.shape[0] for t in (self.x_f, self.x_b) if t is not None)
         vis = self.vis_t
-        vis_t_mean = vis.mean().item() if vis is not None else float('nan')
-        Re_eff = 1.0 / (1.0 / self.Re + vis_t_mean) if vis is not None else float('nan')
-        lr = self.opt.param_groups[0]['lr']
-        loss_total, eq1, eq2, eq3, eq4 = (t.item() for t in (self.loss, self.loss_eq1, self.loss_eq2,
-                                                             self.loss_eq3, self.loss_eq4))
-        bc_loss, eq_total = self.loss_b.item(), self.loss_e.item()
-        sup_loss = self.loss_s.item() if isinstance(self.loss_s, torch.Tensor) else float(self.loss_s)
-        width = getattr(self, 'progress_bar_width', 30)
-        progress = (epoch_id + 1) / num_epoch
-        filled = int(progress * width)
-        bar = '#' * filled + ' ' * (width - filled)
-
-        def fmt_t(sec):
-            if sec == float('inf'):
-                return 'INF'
-            h, rem = divmod(sec, 3600.0)
-            m, s_ = divmod(rem, 60.0)
-            return ("%dh%dm" % (h, m)) if h >= 1 else (("%dm%04.1fs" % (m, s_)) if m >= 1 else ("%.1fs" % s_))
-
-        try:
-            mem_alloc = torch.cuda.memory_allocated(self.device) / 1024**2
-            mem_reserved = torch.cuda.memory_reserved(self.device) / 1024**2
-            mem_total = torch.cuda.get_device_properties(self.device).total_memory / 1024**2
-        except Exception:
-            mem_alloc = mem_reserved = mem_total = float('nan')
-        pts = (self.x_f.shape[0] if self.x_f is not None else 0) + (self.x_b.shape[0] if self.x_b is not None else 0)
-        throughput = interval_it_s * pts
-        print(f"[{self.current_stage}] {epoch_id+1:>7d}/{num_epoch:<7d} {progress*100:6.2f}% |{bar}|")
-        print(f"  loss: total={loss_total:.3e}  eq_total={eq_total:.3e}  boundary={bc_loss:.3e}\n"
-              f"        eq1={eq1:.2e} eq2={eq2:.2e} eq3={eq3:.2e} eq4(entropy residual)={eq4:.2e}")
-        if self.supervision_point_count > 0 and self.alpha_s != 0.0:
-            print(f"  supervision: loss={sup_loss:.3e} alpha={self.alpha_s:.3g} "
-                  f"samples_total={self.supervision_total_points} local={self.supervision_point_count}")
-        if self.eq_weights is not None:
-            w = self.eq_weights
-            print(f"  SDF : w[min]={w.min().item():.3f} w[max]={w.max().item():.3f} w[mean]={w.mean().item():.3f}")
-        print(f"  time: stage={fmt_t(stage_elapsed)}  avg/epoch={stage_elapsed/(epoch_id+1):.2f}s  "
-              f"interval_it/s={interval_it_s:.2f}  avg_it/s={avg_it_s:.2f}\n"
-              f"        eta={fmt_t(eta_sec)}  total={fmt_t(total_elapsed)}")
-        print(f"  GPU : mem={mem_alloc:.1f}MB/{mem_total:.0f}MB (res {mem_reserved:.1f}MB)  "
-              f"throughput={throughput:.1f} pts/s  lr={lr:.2e}")
-        print(f"  phys: Re={self.Re}  Re_eff={Re_eff:.1f}  alpha_evm={self.alpha_evm}")
-        print('-' * 100)
-        if getattr(self, 'tb_writer', None) is not None:
-            try:
-                tb, gs = self.tb_writer, self.global_step
-                for tag, val in (('loss/total', loss_total), ('loss/boundary', bc_loss), ('loss/eq_total', eq_total),
-                                 ('loss/eq1', eq1), ('loss/eq2', eq2), ('loss/eq3', eq3), ('loss/eq4_entropy', eq4),
-                                 ('physics/Re_eff', Re_eff), ('physics/alpha_evm', self.alpha_evm),
-                                 ('perf/throughput_pts_per_s', throughput), ('perf/avg_iter_s', avg_it_s),
-                                 ('perf/interval_iter_s', interval_it_s), ('lr', lr)):
-                    tb.add_scalar(tag, val, gs)
-                if self.supervision_point_count > 0 and self.alpha_s != 0.0:
-                    tb.add_scalar('loss/supervision', sup_loss, gs)
-            except Exception:
-                pass
-        self._last_log_time = now
-        self._last_log_epoch = epoch_id
-
-    def get_runtime_stats(self, epoch_id: int, num_epoch: int):
-        now = time.time()
-        if not hasattr(self, '_epoch_start_wall'):
-            return {}
-        elapsed = now - self._epoch_start_wall
-        avg_it_s = (epoch_id + 1) / elapsed if elapsed > 0 else 0.0
-        remain = num_epoch - (epoch_id + 1)
-        eta_sec = remain / avg_it_s if avg_it_s > 0 else float('inf')
-        vis = self.vis_t
-        vis_t_mean = vis.mean().item() if vis is not None else float('nan')
-        Re_eff = 1.0 / (1.0 / self.Re + vis_t_mean) if vis is not None else float('nan')
-        return dict(avg_it_s=avg_it_s, eta_seconds=eta_sec, vis_t_mean=vis_t_mean, Re_eff=Re_eff)
+        Re_eff = 1.0 / (1.0 / self.Re + vis.mean().item()) if vis is not None else float('nan')
+        terms = ' '.join('%s=%.3e' % (k, float(getattr(self, 'loss_' + k))) for k in ('eq1', 'eq2', 'eq3', 'eq4'))
+        print('[%s] %d/%d  loss=%.4e  eq_total=%.3e boundary=%.3e  %s' % (
+            self.current_stage, epoch_id + 1, num_epoch, float(self.loss), float(self.loss_e), float(self.loss_b), terms))
+        if self.supervision_total_points > 0 and self.alpha_s != 0.0:
+            print('  supervision: loss=%.3e alpha=%.3g samples_total=%d local=%d' % (
+                float(self.loss_s), self.alpha_s, self.supervision_total_points, self.supervision_point_count))
+        print('  it/s=%.2f  throughput=%.1f pts/s  lr=%.2e  Re=%s  Re_eff=%.1f  alpha_evm=%s' % (
+            rate, rate * pts, self.opt.param_groups[0]['lr'], self.Re, Re_eff, self.alpha_evm))
+        self._last_log_time, self._last_log_epoch = now, epoch_id
 
     # ---------------------------------------------------------------- evaluation / io
     def _errors(self, x, y, u, v, p):

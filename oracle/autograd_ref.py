@@ -149,13 +149,17 @@ class EvNSFnetOracle:
     vis_t_minus <- alpha_evm*|e| (detached)   (pinn_solver.py:334)
     eq4    = eq1*(u-.5)+eq2*(v-.5)-e          (pinn_solver.py:341)
     loss_e = m(eq1)+m(eq2)+m(eq3)+0.1*m(eq4), m(r)=mean(w*r^2) (:387-397)
+    loss_s = mean((u_s-u)^2)+mean((v_s-v)^2)+mean over FINITE p_s of (p_s-p)^2   (:399-411)
+    loss   = alpha_b*loss_b + alpha_e*loss_e + alpha_s*loss_s                    (:426)
     """
 
     def __init__(self, net, net_e, Re, alpha_evm, alpha_b=10.0, alpha_e=1.0, lr=1e-3,
-                 coord_scale=1.0):
+                 coord_scale=1.0, alpha_s=0.0):
         self.net, self.net_e, self.Re = net, net_e, Re
         self.vis_t0 = 20.0 / Re
         self.alpha_evm, self.alpha_b, self.alpha_e = alpha_evm, alpha_b, alpha_e
+        self.alpha_s = alpha_s
+        self.sup = None
         self.scale, self.scale_sq = float(coord_scale), float(coord_scale) ** 2
         self.w = None
         self.vis_t_minus = None
@@ -184,6 +188,30 @@ class EvNSFnetOracle:
         with torch.no_grad():
             e = self.net_e(torch.cat((self.x_f, self.y_f), dim=1))[:, 0:1]
         self.vis_t_minus = self.alpha_evm * torch.abs(e).detach()
+
+    def set_supervised(self, x_s, y_s, u_s, v_s, p_s=None):
+        """ev-NSFnet/pinn_solver.py:202-251: fp32 copies of the samples; the pressure mask is
+        np.isfinite of the targets (:247-249); None clears the data (:194-200)."""
+        if x_s is None or len(np.asarray(x_s)) == 0:
+            self.sup = None
+            return
+        dt = next(self.net.parameters()).dtype
+        t = lambda a: torch.tensor(np.asarray(a), dtype=dt).reshape(-1, 1)
+        mask = None if p_s is None else torch.tensor(np.isfinite(np.asarray(p_s)).reshape(-1))
+        self.sup = (t(x_s), t(y_s), t(u_s), t(v_s), None if p_s is None else t(p_s), mask)
+
+    def supervised_loss(self):
+        """ev-NSFnet/pinn_solver.py:399-411 (enabled only with data and alpha_s != 0, :251, :255)."""
+        if self.sup is None or self.alpha_s == 0.0:
+            return torch.zeros((), dtype=next(self.net.parameters()).dtype)
+        x_s, y_s, u_s, v_s, p_s, mask = self.sup
+        out = self.net(torch.cat((x_s, y_s), dim=1))
+        loss_u = torch.mean(torch.square(u_s.view(-1) - out[:, 0]))
+        loss_v = torch.mean(torch.square(v_s.view(-1) - out[:, 1]))
+        loss_p = torch.zeros((), dtype=out.dtype)
+        if p_s is not None and mask is not None and bool(mask.any()):
+            loss_p = torch.mean(torch.square(p_s.view(-1)[mask] - out[:, 2][mask]))
+        return loss_u + loss_v + loss_p
 
     def loss(self):
         self.loss_b = bc_loss(self.net, self.x_b, self.y_b, self.u_b, self.v_b)
@@ -214,7 +242,8 @@ class EvNSFnetOracle:
 
         self.loss_eq = [wmse(r) for r in self.eq]
         self.loss_e = self.loss_eq[0] + self.loss_eq[1] + self.loss_eq[2] + 0.1 * self.loss_eq[3]
-        self.total = self.alpha_b * self.loss_b + self.alpha_e * self.loss_e
+        self.loss_s = self.supervised_loss()
+        self.total = self.alpha_b * self.loss_b + self.alpha_e * self.loss_e + self.alpha_s * self.loss_s
         return self.total
 
     def step(self, epoch_id=None):

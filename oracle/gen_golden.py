@@ -179,6 +179,68 @@ def gen_ev(mods, name, L, H, L1, H1, N, Re, alpha_evm, seed, steps, alpha_b=10.0
     print(name, "loss0", losses[0])
 
 
+def gen_ev_supervised(mods, name, L=3, H=24, L1=2, H1=10, N=160, NS=37, Re=2000, alpha_evm=0.04, alpha_s=0.7,
+                      seed=31, steps=3, alpha_b=10.0, alpha_e=1.0, lr=1e-3, p_mode="nan"):
+    """Supervised-data branch of the reference loss (ev-NSFnet/pinn_solver.py:202-251 set_supervised_data,
+    :399-411 loss_s): per-output means, pressure averaged over its FINITE targets only.  p_mode: "nan" = some
+    NaN pressure targets, "none" = no pressure array, "allnan" = every pressure target masked."""
+    P = _make_ev(mods, L, H, L1, H1, Re, alpha_evm, alpha_b, alpha_e, lr, seed)
+    P.alpha_s = alpha_s
+    dl = mods["cavity_data"].DataLoader(N_f=N, N_b=1000)
+    bc = tuple(a[::16] for a in dl.loading_boundary_data())
+    x, y = _points(N, seed + 1)
+    rng = np.random.RandomState(seed + 3)
+    xs, ys = rng.rand(NS, 1), rng.rand(NS, 1)
+    us, vs = rng.randn(NS, 1) * 0.3, rng.randn(NS, 1) * 0.2
+    ps_ = rng.randn(NS, 1) * 0.1
+    if p_mode == "nan":
+        ps_[rng.rand(NS) < 0.35] = np.nan
+    elif p_mode == "allnan":
+        ps_[:] = np.nan
+    elif p_mode == "none":
+        ps_ = None
+    P.set_boundary_data(X=bc)
+    P.set_eq_training_data(X=(x, y))
+    P.set_supervised_data((xs, ys, us, vs, ps_))
+    assert P.supervision_enabled
+    rec = dict(L=L, H=H, L1=L1, H1=H1, N=N, Re=Re, alpha_evm=alpha_evm, seed=seed, alpha_s=alpha_s,
+               alpha_b=alpha_b, alpha_e=alpha_e, lr=lr, x=x, y=y, x_b=bc[0], y_b=bc[1], u_b=bc[2], v_b=bc[3],
+               x_s=xs, y_s=ys, u_s=us, v_s=vs, w0=_flat(P.net), w0_e=_flat(P.net_1))
+    if ps_ is not None:
+        rec["p_s"] = ps_
+    losses, params = [], []
+    real = P.fwd_computing_loss_2d
+    calls = {"n": 0}
+
+    def spy():
+        k = calls["n"]
+        calls["n"] += 1
+        if k >= 1:
+            params.append(_flat(P.net))
+            if k == 1:
+                rec["grad0"] = _flat(P.net, grad=True)
+        if k == steps:
+            raise StopIteration
+        out = real()
+        losses.append([float(out[0]), float(P.loss_b), float(P.loss_e), float(P.loss_s)])
+        return out
+
+    try:
+        P.solve_Adam(spy, num_epoch=steps + 1)
+    except StopIteration:
+        pass
+    # the same first step with the supervised weight switched off (set_supervised_loss_weight(0), :253-255)
+    P2 = _make_ev(mods, L, H, L1, H1, Re, alpha_evm, alpha_b, alpha_e, lr, seed)
+    P2.alpha_s = alpha_s
+    P2.set_boundary_data(X=bc); P2.set_eq_training_data(X=(x, y)); P2.set_supervised_data((xs, ys, us, vs, ps_))
+    P2.set_supervised_loss_weight(0.0)
+    out = P2.fwd_computing_loss_2d()
+    rec["loss_alpha0"] = np.array([float(out[0]), float(P2.loss_s)])
+    rec.update(losses=np.array(losses), params_after=np.stack(params))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "losses0 [total, b, e, s]", losses[0])
+
+
 def gen_ev_freeze(mods, name, seed=7):
     """Steps 10000..10002 of solve_Adam on a tiny net: net_1 trains for exactly
     one step and Adam is re-created twice (pinn_solver.py:459-462, 489-511)."""
@@ -247,6 +309,9 @@ def main():
         gen_ev(ev, "ev_4x50_4x40_re4000", 4, 50, 4, 40, 1024, 4000, 0.05, 11, 4)
         gen_ev(ev, "ev_2x16_sdf_scaled", 2, 16, 2, 12, 256, 3000, 0.03, 21, 4, sdf=True, coord_scale=2.0)
         gen_ev_freeze(ev, "ev_freeze_2x8")
+        gen_ev_supervised(ev, "ev_sup_3x24_nanp", p_mode="nan")
+        gen_ev_supervised(ev, "ev_sup_3x24_nop", p_mode="none", seed=41)
+        gen_ev_supervised(ev, "ev_sup_3x24_allnanp", p_mode="allnan", seed=43, steps=1)
         gen_data_prep(ns, ev)
         os.chdir("/tmp")
 

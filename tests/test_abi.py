@@ -84,6 +84,24 @@ def test_argument_errors_are_reported(lib):
     lib.pinn_plan_destroy(p); lib.pinn_net_destroy(h)
 
 
+def test_no_cached_state_in_the_library_sources():
+    """include/nsfnet_pinn.h promises no global mutable state besides the (thread-local) last-error
+    string: no function-local or file-scope `static` variables in csrc/ (launch attributes are set per
+    plan, on the plan's device, by pinn_plan_create)."""
+    csrc = os.path.join(ROOT, "nsfnet_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+            m = re.match(r"\s*static\s+(?!constexpr|inline|thread_local|__device__|__global__)([\w:<> ]+?)\s+(\w+)\s*(=|;|\[)", line)
+            if m:
+                bad.append("%s:%d: %s" % (f, i, line.strip()))
+    assert not bad, bad
+    text = open(os.path.join(csrc, "capi.hip")).read()
+    assert len(re.findall(r"thread_local", text)) == 1          # the last-error buffer
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from nsfnet_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _case():
+def _case(sup_n=9):
     rng = np.random.RandomState(42)
     N, Nb = 70, 33            # neither divisible by 2: last rank takes the remainder
     x, y = rng.rand(N, 1), rng.rand(N, 1)
@@ -31,6 +31,7 @@ def _case():
     xs, ys = rng.rand(9, 1), rng.rand(9, 1)
     us, vs, ps_ = rng.rand(9, 1), rng.rand(9, 1), rng.rand(9, 1)
     ps_[[1, 6], 0] = np.nan
+    xs, ys, us, vs, ps_ = (a[:sup_n] for a in (xs, ys, us, vs, ps_))
     return dict(x=x, y=y, xb=xb, yb=yb, ub=ub, vb=vb, w=w, sup=(xs, ys, us, vs, ps_))
 
 
@@ -51,13 +52,13 @@ def _build_solver(case):
     return P
 
 
-def _run_rank(rank, world, port, out_dir):
+def _run_rank(rank, world, port, out_dir, sup_n=9):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        P = _build_solver(_case())
+        P = _build_solver(_case(sup_n))
         assert P.is_distributed and P.engine.world_size == world
         rec = dict(n_f_local=P.x_f.shape[0], n_b_local=P.x_b.shape[0], n_s_local=P.supervision_point_count)
         import io, contextlib
@@ -94,6 +95,46 @@ def test_two_rank_sharded_training_matches_single_process(tmp_path, monkeypatch)
     np.testing.assert_allclose(r0["params"], P.engine.net.params.numpy(), rtol=0, atol=2e-6)
     for key, val in (("loss", P.loss), ("loss_b", P.loss_b), ("loss_e", P.loss_e), ("loss_s", P.loss_s)):
         assert abs(float(r0[key]) - float(val)) <= 1e-5 * abs(float(val)), key
+
+
+@pytest.mark.timeout(300)
+def test_rank_with_empty_supervised_share(tmp_path, monkeypatch):
+    """One supervised sample over two ranks: np.array_split hands rank 1 nothing
+    (ev-NSFnet/pinn_solver.py:219-221, the branch is then skipped there, :400).  That rank must still
+    take part in the step's all-reduce and normalise by the global counts - not raise, not hang."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_run_rank, args=(world, port, str(tmp_path), 1), nprocs=world, join=True)
+    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world))
+    assert (int(r0["n_s_local"]), int(r1["n_s_local"])) == (1, 0)
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    np.testing.assert_array_equal(r0["sums"], r1["sums"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    P = _build_solver(_case(1))
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        P.train(num_epoch=3, lr=1e-3)
+    np.testing.assert_allclose(r0["params"], P.engine.net.params.numpy(), rtol=0, atol=2e-6)
+    assert float(P.loss_s) > 0 and abs(float(r0["loss_s"]) - float(P.loss_s)) <= 1e-5 * float(P.loss_s)
+
+
+def test_too_few_points_for_the_ranks_raises_everywhere(monkeypatch):
+    """Fewer collocation / boundary points than ranks: the error depends on global counts only, so
+    every rank raises it before any collective (no rank-divergent hang)."""
+    import fakes
+    fakes.install(monkeypatch)
+    from nsfnet_amd import ev_pinn_solver as es
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    P = es.PysicsInformedNeuralNetwork(Re=800, layers=1, layers_1=1, hidden_size=4, hidden_size_1=4, N_f=3)
+    P.is_distributed, P.world_size = True, 4
+    for rank in range(4):
+        P.rank = rank
+        with pytest.raises(ValueError, match="cannot be sharded"):
+            P._shard(3)
+    P.rank = 3
+    assert P._shard(9) == (6, 9)
 
 
 def test_single_process_fake_path_matches_autograd_oracle(monkeypatch):

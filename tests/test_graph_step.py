@@ -61,3 +61,40 @@ def test_graph_step_follows_oracle_adam_trajectory(monkeypatch):
     mine = E.net.params.cpu().numpy().astype(np.float64)
     upd = mine - flat
     assert np.linalg.norm(upd - (p - flat)) / np.linalg.norm(p - flat) < 2e-3
+
+
+def test_init_vis_t_between_replays_matches_eager(monkeypatch):
+    """PINN.init_vis_t() (ev-NSFnet/pinn_solver.py:138-140) after a step has been captured: the graph keeps
+    reading and writing the lagged-viscosity allocation it was captured with, so the re-initialisation must
+    land IN that allocation (or drop the graph) - bit-equal to the eager sequence either way."""
+    from nsfnet_amd import engine as eng
+    from oracle import autograd_ref as ar
+
+    def run(graph):
+        monkeypatch.setenv("NSFNET_GRAPH", "1" if graph else "0")
+        dev = torch.device("cuda:0")
+        E = eng.PinnEngine(dev, 3, 24, 1000.0, alpha_b=10.0, alpha_e=1.0, flavour="ev", n_hidden_e=2, hidden_e=12,
+                           alpha_evm=0.05)
+        E.net.set_flat(ar.flat_params(ar.seeded_net(3, 3, 24, seed=8)))
+        E.net_e.set_flat(ar.flat_params(ar.seeded_net(1, 2, 12, seed=9)))
+        x, y = (a.reshape(-1).astype(np.float32) for a in ar.uniform_grid(20, 20))
+        xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+        E.set_collocation(x, y)
+        E.set_boundary(xb, yb, ub, vb)
+        ptr0 = E.plan_f.vis_t_minus.data_ptr()
+        for _ in range(3):
+            E.step(1e-3)
+        E.alpha_evm = 0.02          # set_alpha_evm at a stage boundary, then the public re-initialisation
+        E.init_vis_t()
+        assert (not graph) or E.plan_f.vis_t_minus.data_ptr() == ptr0 or len(E._graphs) == 0
+        for _ in range(3):
+            E.step(1e-3)
+        # supervised data dropped after capture: the captured steps must be dropped as well
+        E.set_supervised(None, None, None, None)
+        E.step(1e-3)
+        torch.cuda.synchronize()
+        return E.net.params.cpu().numpy().copy(), E.plan_f.vis_t.cpu().numpy().copy()
+
+    p_e, v_e = run(False)
+    p_g, v_g = run(True)
+    assert np.array_equal(p_e, p_g) and np.array_equal(v_e, v_g)

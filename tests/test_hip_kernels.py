@@ -313,3 +313,61 @@ def test_64_column_tile_kernels_at_narrow_widths(H, prec, monkeypatch):
     for k, name in enumerate(("eq1", "eq2", "eq3")):
         assert _rel_max(E.plan_f.field(name).cpu().numpy(), r["eqs"][k]) < tol, name
     assert _rel_l2(E.grads.cpu().numpy(), r["grad"] + b["grad"]) < 1e-4
+
+
+def test_two_threads_alternating_nets_of_different_depth():
+    """The library keeps no cached launch state (include/nsfnet_pinn.h): two host threads driving nets of
+    different depth (different dynamic-LDS sizes of the same kernel template) on their own streams, in
+    alternation, give the results of the serial runs."""
+    import threading
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(12)
+    x = rng.rand(700).astype(np.float32); y = rng.rand(700).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+
+    def make(L, prec):
+        E = eng.PinnEngine(dev, L, 64, 300.0, alpha_b=10.0, alpha_e=1.0, precision=prec)
+        E.net.set_flat(torch.tensor(_rand_params(3, L, 64, seed=L)))
+        E.set_collocation(x, y); E.set_boundary(xb, yb, ub, vb)
+        return E
+
+    def run(E, out, k):
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            for _ in range(6):
+                E.loss_and_grad()
+            torch.cuda.current_stream().synchronize()
+            out[k] = E.grads.cpu().numpy().copy()
+
+    serial, threaded = {}, {}
+    for prec in ("fp32", "bf16x3"):
+        for L in (2, 9):            # created in alternating order: shallow, deep, shallow, deep
+            run(make(L, prec), serial, (prec, L))
+    engines = {(prec, L): make(L, prec) for prec in ("fp32", "bf16x3") for L in (9, 2)}
+    ths = [threading.Thread(target=run, args=(E, threaded, k)) for k, E in engines.items()]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for k in serial:
+        assert np.array_equal(serial[k], threaded[k]), k
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16"])
+def test_nan_weight_poisons_the_loss(prec):
+    """A NaN parameter must surface as a NaN loss in every precision mode (the bf16 fragment copy uses the
+    hardware conversion, which keeps NaNs; the integer rounding idiom turns some of them into 0 or inf)."""
+    eng = _engine_mod()
+    dev = torch.device("cuda:0")
+    L, H = 3, 64
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    x, y = (a.reshape(-1).astype(np.float32) for a in ar.uniform_grid(16, 16))
+    for bits in (0x7FC00000, 0xFFFFFFFF, 0x7F800001):      # quiet NaN, all-ones NaN (-> +0 in the idiom), signalling NaN (-> inf)
+        flat = _rand_params(3, L, H, seed=2)
+        i = 3 * H + 5 * H + 7                                # an entry of layer_1.weight (goes through the bf16 copy)
+        flat.view(np.uint32)[i] = bits
+        E = eng.PinnEngine(dev, L, H, 100.0, alpha_b=10.0, alpha_e=1.0, precision=prec)
+        E.net.set_flat(torch.tensor(flat))
+        E.set_collocation(x, y); E.set_boundary(xb, yb, ub, vb)
+        E.loss_and_grad()
+        lt = E.loss_terms()
+        assert np.isnan(float(lt["loss"])), (prec, hex(bits), float(lt["loss"]))
+        assert np.isnan(float(lt["loss_b"])) and np.isnan(float(lt["loss_e"]))

@@ -101,6 +101,39 @@ def test_ev_restatement_vs_reference_steps(golden_dir, name):
     np.testing.assert_array_equal(ar.flat_params(net_e).numpy(), g["params_e_after"])   # frozen: untouched
 
 
+@pytest.mark.parametrize("name", ["ev_sup_3x24_nanp", "ev_sup_3x24_nop", "ev_sup_3x24_allnanp"])
+def test_ev_supervised_loss_vs_reference(golden_dir, name):
+    """loss_s with NaN-masked pressure targets (ev-NSFnet/pinn_solver.py:399-411), its gradient and the Adam
+    steps it drives, against the reference's own numbers."""
+    g = _load(golden_dir, name)
+    net = _net_from_flat(g["w0"], 3, int(g["L"]), int(g["H"]))
+    net_e = _net_from_flat(g["w0_e"], 1, int(g["L1"]), int(g["H1"]))
+    o = ar.EvNSFnetOracle(net, net_e, float(g["Re"]), float(g["alpha_evm"]), alpha_b=float(g["alpha_b"]),
+                          alpha_e=float(g["alpha_e"]), lr=float(g["lr"]), alpha_s=float(g["alpha_s"]))
+    o.set_data(g["x"], g["y"], g["x_b"], g["y_b"], g["u_b"], g["v_b"])
+    p_s = g["p_s"] if "p_s" in g.files else None
+    o.set_supervised(g["x_s"], g["y_s"], g["u_s"], g["v_s"], p_s)
+    if name.endswith("_nanp"):
+        assert 0 < np.isnan(p_s).sum() < p_s.size          # the fixture really exercises the mask
+    vtm0 = o.vis_t_minus.clone()
+    for k in range(g["losses"].shape[0]):
+        total = o.step(epoch_id=k)
+        mine = [total, float(o.loss_b.detach()), float(o.loss_e.detach()), float(o.loss_s.detach())]
+        np.testing.assert_allclose(mine, g["losses"][k], rtol=5e-6)
+        if k == 0:
+            assert _rel(o.grads.numpy(), g["grad0"]) < 1e-5
+        assert _rel(ar.flat_params(net).numpy(), g["params_after"][k]) < 1e-5
+    # weight switched to 0: the branch is skipped and loss_s reads 0 (:253-255, :398-400)
+    net = _net_from_flat(g["w0"], 3, int(g["L"]), int(g["H"]))
+    o = ar.EvNSFnetOracle(net, net_e, float(g["Re"]), float(g["alpha_evm"]), alpha_b=float(g["alpha_b"]),
+                          alpha_e=float(g["alpha_e"]), alpha_s=0.0)
+    o.set_data(g["x"], g["y"], g["x_b"], g["y_b"], g["u_b"], g["v_b"])
+    o.vis_t_minus = vtm0
+    o.set_supervised(g["x_s"], g["y_s"], g["u_s"], g["v_s"], p_s)
+    total = float(o.loss().detach())
+    np.testing.assert_allclose([total, float(o.loss_s)], g["loss_alpha0"], rtol=5e-6)
+
+
 def test_ev_freeze_schedule(golden_dir):
     """Steps 10000..10002: the entropy net trains for exactly one step and Adam
     restarts twice (ev-NSFnet/pinn_solver.py:459-462, 489-511)."""

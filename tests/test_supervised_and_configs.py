@@ -1,0 +1,211 @@
+"""GPU parity of the branches and shapes round 1 left unpinned:
+
+  * the supervised-data loss of ev-NSFnet (ev-NSFnet/pinn_solver.py:202-251, :399-411) with NaN-masked
+    pressure targets, against numbers produced by the reference itself (tests/golden/ev_sup_*.npz) and
+    against the fp64 forward-mode oracle, in fp32 and bf16x3;
+  * BASELINE config 4's shape (ev flavour, 6x256 main net + 4x40 entropy net, Re = 4000), entropy net
+    frozen and trainable, fp32 and bf16x3, against the fp64 oracle;
+  * bf16x3 loss / gradient on TRAINED (sharper) weights, where second derivatives amplify operand rounding.
+
+Tolerances: loss terms rel <= 3e-5 (fp32) / 1e-4 (bf16x3, the north-star bar); gradients rel-L2 <= 1e-4;
+parameter updates after k Adam steps rel-L2 <= 2e-3 (see test_solver_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as ar
+from oracle import fwdmode_ref as fr
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _rel_l2(a, b):
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def _rel_max(a, b):
+    a = np.asarray(a, np.float64).reshape(-1); b = np.asarray(b, np.float64).reshape(-1)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _sup_oracle_fp64(flat, g, alpha_s):
+    """loss_s pieces and gradient from the fp64 forward-mode oracle (value-mode forward + backward)."""
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, int(g["L"]), int(g["H"]))
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64).reshape(-1)
+    xs, ys, us, vs = f32(g["x_s"]), f32(g["y_s"]), f32(g["u_s"]), f32(g["v_s"])
+    out, saved = fr.forward1(P, xs, ys)
+    n = xs.size
+    du, dv = out[:, 0] - us, out[:, 1] - vs
+    adj = np.zeros_like(out)
+    adj[:, 0] = 2.0 * alpha_s * du / n
+    adj[:, 1] = 2.0 * alpha_s * dv / n
+    sums = [float(du @ du), float(dv @ dv), 0.0, 0.0]
+    if "p_s" in g.files:
+        ps = f32(g["p_s"])
+        m = np.isfinite(ps)
+        if m.any():
+            dp = np.where(m, out[:, 2] - np.where(m, ps, 0.0), 0.0)
+            adj[:, 2] = 2.0 * alpha_s * dp / m.sum()
+            sums[2], sums[3] = float(dp @ dp), float(m.sum())
+    return sums, fr.backward1(P, xs, ys, saved, adj)
+
+
+@pytest.mark.parametrize("prec,ltol", [("fp32", 3e-5), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("name", ["ev_sup_3x24_nanp", "ev_sup_3x24_nop", "ev_sup_3x24_allnanp"])
+def test_ev_supervised_loss_vs_reference(golden_dir, name, prec, ltol, tmp_path, monkeypatch):
+    from nsfnet_amd import ev_pinn_solver as es
+    from nsfnet_amd import engine as eng
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("NSFNET_PRECISION", prec)
+    g = _load(golden_dir, name)
+    alpha_s = float(g["alpha_s"])
+    P = es.PysicsInformedNeuralNetwork(Re=float(g["Re"]), layers=int(g["L"]), layers_1=int(g["L1"]),
+                                       hidden_size=int(g["H"]), hidden_size_1=int(g["H1"]), N_f=int(g["N"]),
+                                       alpha_evm=float(g["alpha_evm"]), bc_weight=float(g["alpha_b"]),
+                                       eq_weight=float(g["alpha_e"]), learning_rate=float(g["lr"]),
+                                       supervised_data_weight=alpha_s)
+    P.net.dev_net.set_flat(torch.tensor(g["w0"])); P.net_1.dev_net.set_flat(torch.tensor(g["w0_e"]))
+    P.set_boundary_data(X=(g["x_b"], g["y_b"], g["u_b"], g["v_b"]))
+    P.set_eq_training_data(X=(g["x"], g["y"]))
+    p_s = g["p_s"] if "p_s" in g.files else None
+    P.set_supervised_data((g["x_s"], g["y_s"], g["u_s"], g["v_s"], p_s))      # ev-NSFnet/train.py:196-204
+    assert P.supervision_enabled and P.supervision_point_count == g["x_s"].shape[0]
+    P.freeze_evm_net(0)
+    w0 = g["w0"].astype(np.float64)
+    for k in range(g["losses"].shape[0]):
+        P._apply_freeze_schedule(k)
+        loss, (loss_e, loss_b) = P.fwd_computing_loss_2d()
+        mine = [loss.item(), loss_b.item(), loss_e.item(), P.loss_s.item()]
+        np.testing.assert_allclose(mine, g["losses"][k], rtol=ltol)
+        if k == 0:
+            assert _rel_l2(_np(P.engine.grads), g["grad0"]) < 1e-4
+            # the supervised block of the sums vector and its share of the gradient against the fp64 oracle
+            sums_ref, grad_s = _sup_oracle_fp64(g["w0"], g, alpha_s)
+            s = _np(P.engine.sums)[eng.S_SUP:eng.S_SUP + 4]
+            np.testing.assert_allclose(s[:3], sums_ref[:3], rtol=ltol, atol=1e-12)
+            assert s[3] == sums_ref[3]                                         # census of finite pressure targets
+            P.engine.alpha_s = 0.0
+            P.engine.loss_and_grad()
+            g_without = _np(P.engine.grads).astype(np.float64)
+            P.engine.alpha_s = alpha_s
+            P.engine.loss_and_grad()
+            assert _rel_l2(_np(P.engine.grads).astype(np.float64) - g_without, grad_s) < 1e-4
+            # roll the lagged-viscosity state back: the two extra evaluations above advanced it
+            P.init_vis_t()
+        P.engine.adam_step(P.opt.param_groups[0]["lr"])
+        upd = _np(P.engine.net.params).astype(np.float64) - w0
+        assert _rel_l2(upd, g["params_after"][k].astype(np.float64) - w0) < 2e-3
+    # weight switched off (set_supervised_loss_weight(0), :253-255): the branch is skipped, loss_s reads 0
+    P.net.dev_net.set_flat(torch.tensor(g["w0"]))
+    P.init_vis_t()
+    P.set_supervised_loss_weight(0.0)
+    loss, _ = P.fwd_computing_loss_2d()
+    np.testing.assert_allclose([loss.item(), float(P.loss_s)], g["loss_alpha0"], rtol=ltol, atol=1e-12)
+    sums = _np(P.engine.sums)
+    assert np.all(sums[eng.S_SUP:eng.S_SUP + eng.NLOSS] == 0.0)              # nothing stale left to be all-reduced
+    # data cleared (clear_supervised_data, :194-200)
+    P.set_supervised_loss_weight(alpha_s)
+    P.clear_supervised_data()
+    P.init_vis_t()
+    loss, _ = P.fwd_computing_loss_2d()
+    np.testing.assert_allclose(loss.item(), g["loss_alpha0"][0], rtol=ltol)
+
+
+@pytest.mark.parametrize("prec,ltol,rtol_eq", [("fp32", 1e-5, 2e-5), ("bf16x3", 1e-4, 2e-4)])
+@pytest.mark.parametrize("e_trainable", [False, True])
+def test_config4_shape_vs_oracle(e_trainable, prec, ltol, rtol_eq):
+    """BASELINE config 4: ev-NSFnet, Re = 4000, 6x256 main net + 4x40 entropy net
+    (ev-NSFnet/pinn_solver.py:290-342, 372-428; entropy-net training step :459-462)."""
+    from nsfnet_amd import engine as eng
+    dev = torch.device("cuda:0")
+    L, H, L1, H1, N, Re, aevm = 6, 256, 4, 40, 416, 4000.0, 0.05
+    flat = ar.flat_params(ar.seeded_net(3, L, H, seed=1234)).numpy().copy()
+    flat_e = ar.flat_params(ar.seeded_net(1, L1, H1, seed=4321)).numpy().copy()
+    rng = np.random.RandomState(44)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::8].astype(np.float32) for a in ar.cavity_boundary())
+    E = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, flavour="ev", n_hidden_e=L1, hidden_e=H1,
+                       alpha_evm=aevm, precision=prec)
+    E.net.set_flat(torch.tensor(flat)); E.net_e.set_flat(torch.tensor(flat_e))
+    E.e_trainable = e_trainable
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    vtm0 = _np(E.plan_f.vis_t_minus).astype(np.float64)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    Pe = fr.unflatten(flat_e.astype(np.float64), 2, 1, L1, H1)
+    e, saved_e = fr.forward1(Pe, x64, y64)
+    np.testing.assert_allclose(vtm0, aevm * np.abs(e[:, 0]), rtol=1e-3 if prec != "fp32" else 1e-4, atol=1e-7)
+    vis_t = np.minimum(np.float32(20.0 / Re), vtm0)
+    r = fr.pde_loss_and_grad(P, x64, y64, Re, alpha_e=1.0, vis_t=vis_t, e=e[:, 0])
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    for k, name in enumerate(("eq1", "eq2", "eq3", "eq4")):
+        assert _rel_max(_np(E.plan_f.field(name)), r["eqs"][k]) < rtol_eq, name
+    np.testing.assert_allclose(_np(E.sums)[0:4], r["sums"], rtol=ltol)
+    ref_loss = 10.0 * sum(b["sums"]) / xb.size + (sum(r["sums"][:3]) + 0.1 * r["sums"][3]) / N
+    assert abs(float(E.loss_terms()["loss"]) - ref_loss) < ltol * ref_loss
+    assert _rel_l2(_np(E.grads), r["grad"] + b["grad"]) < 1e-4
+    if e_trainable:
+        ge = fr.backward1(Pe, x64, y64, saved_e, r["e_adj"].reshape(-1, 1))
+        assert _rel_l2(_np(E.grads_e), ge) < 1e-4
+    else:
+        assert float(E.grads_e.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Re", [2000, 3000])
+@pytest.mark.parametrize("prec,ltol", [("fp32", 2e-5), ("bf16x3", 1e-4)])
+def test_trained_weights_loss_and_gradient(prec, ltol, Re):
+    """Per-step parity on TRAINED nets (tests/golden/trained: 2.7 M Adam steps of this engine, reference
+    state_dict format): second derivatives of a converged, sharper field amplify operand rounding
+    (SURVEY.md section 7), so the bf16x3 bar is re-checked there, not only on fresh-init weights."""
+    from nsfnet_amd import engine as eng
+    dev = torch.device("cuda:0")
+    L, H, L1, H1, N, aevm = 6, 80, 4, 40, 2000, 0.002
+    sd = torch.load(os.path.join(HERE, "golden", "trained", "ev_re%d_6x80_net.pth" % Re), weights_only=True)
+    sde = torch.load(os.path.join(HERE, "golden", "trained", "ev_re%d_4x40_evm.pth" % Re), weights_only=True)
+    E = eng.PinnEngine(dev, L, H, float(Re), alpha_b=10.0, alpha_e=1.0, flavour="ev", n_hidden_e=L1, hidden_e=H1,
+                       alpha_evm=aevm, precision=prec)
+    E.net.load_state_dict(sd); E.net_e.load_state_dict(sde)
+    flat, flat_e = _np(E.net.params).copy(), _np(E.net_e.params).copy()
+    rng = np.random.RandomState(Re)
+    # half the sample hugs the lid corners, where the converged field is sharpest
+    x = np.concatenate([rng.rand(N // 2), np.clip(rng.rand(N // 2) ** 4, 1e-4, 1)]).astype(np.float32)
+    y = np.concatenate([rng.rand(N // 2), 1.0 - np.clip(rng.rand(N // 2) ** 4 * 0.2, 1e-4, 1)]).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1).astype(np.float32) for a in ar.cavity_boundary())
+    E.e_trainable = True
+    E.set_collocation(x, y)
+    E.set_boundary(xb, yb, ub, vb)
+    vtm0 = _np(E.plan_f.vis_t_minus).astype(np.float64)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    P = fr.unflatten(flat.astype(np.float64), 2, 3, L, H)
+    Pe = fr.unflatten(flat_e.astype(np.float64), 2, 1, L1, H1)
+    e, saved_e = fr.forward1(Pe, x64, y64)
+    vis_t = np.minimum(np.float32(20.0 / Re), vtm0)
+    r = fr.pde_loss_and_grad(P, x64, y64, float(Re), alpha_e=1.0, vis_t=vis_t, e=e[:, 0])
+    b = fr.bc_loss_and_grad(P, xb.astype(np.float64), yb.astype(np.float64), ub, vb, alpha_b=10.0)
+    lt = E.loss_terms()
+    ref_e = (sum(r["sums"][:3]) + 0.1 * r["sums"][3]) / N
+    ref_b = sum(b["sums"]) / xb.size
+    assert abs(float(lt["loss_e"]) - ref_e) < ltol * ref_e
+    assert abs(float(lt["loss_b"]) - ref_b) < ltol * ref_b
+    assert abs(float(lt["loss"]) - (10.0 * ref_b + ref_e)) < ltol * (10.0 * ref_b + ref_e)
+    assert _rel_l2(_np(E.grads), r["grad"] + b["grad"]) < 1e-4
+    ge = fr.backward1(Pe, x64, y64, saved_e, r["e_adj"].reshape(-1, 1))
+    assert _rel_l2(_np(E.grads_e), ge) < 1e-4
