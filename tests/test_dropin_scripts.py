@@ -69,7 +69,7 @@ def test_ev_scripts(tmp_path):
         "supervision: {enabled: true, num_samples: 50, loss_weight: 0.5}\n")
     env = {"PYTHONPATH": ROOT}
     out = _run([sys.executable, "train.py", "--config", "cfg.yaml", "--data", dns], str(work), env)
-    assert out.count("Error p:") == 2 and "supervision: loss=" in out and "SDF :" in out
+    assert out.count("Error p:") == 2 and "supervision: loss=" in out
     cks = [p for p in (work / "results").rglob("model_cavity_loop0.pth")]
     assert cks and os.path.exists(str(cks[0]) + "_evm")
     out = _run([sys.executable, "test.py", str(cks[0]), "--data", dns, "--config", "cfg.yaml", "--out", str(work / "o")],
