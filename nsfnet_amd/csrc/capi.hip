@@ -48,6 +48,7 @@ struct pinn_plan_s {
   long n;
   int streams, ntiles, npad;
   int grid_f, grid_b, groups;
+  int pipe_f, grid_fp;   // software-pipelined forward (fwd_bf16_pipe.hip) usable for this plan; its grid (pairs of tiles)
   // workspace offsets in bytes
   size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
 };
@@ -71,9 +72,10 @@ static int env_int(const char* name, int dflt) {
 
 // kernel-family dispatch (precision x tile geometry), shared by the launches and by pinn_plan_create's
 // configure pass (args.configure = 1: set the dynamic-LDS attribute of exactly the kernel a launch would pick)
-static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s) {
+static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s, bool pipe = false) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (pipe) return launch_fwd_pipe(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s);
   if (n.prec_fwd)
     return n.HP > 256 ? launch_fwd_bf16_wide(n.HP, NS, terms_of(n.prec_fwd), a, plan->grid_f, s)
                       : launch_fwd_bf16(n.HP, NS, terms_of(n.prec_fwd), cols, a, plan->grid_f, s);
@@ -161,6 +163,11 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (lds_b > 163840 || lds_f > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
+  // residual mode, bf16 MFMA, hidden 256, >= 2 hidden layers: the one-wave-per-SIMD pipelined forward
+  // (PINN_PIPE=0 opts out); forward-only calls (save = 0) keep the 8-wave kernel
+  p->pipe_f = net->prec_fwd != 0 && HP == 256 && !wide && streams == 4 && L >= 2 && env_int("PINN_PIPE", 1) != 0 &&
+              fwd_pipe_lds_bytes(HP, L) <= 163840;
+  p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
   if (L > 1) {
@@ -172,14 +179,15 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     p->groups = 0;
   }
   size_t off = 0;
-  p->off_partials = off; off = align_up(off + (size_t)p->grid_f * PINN_NLOSS * 4, 256);
+  p->off_partials = off; off = align_up(off + (size_t)(p->grid_f > p->grid_fp ? p->grid_f : p->grid_fp) * PINN_NLOSS * 4, 256);
   p->off_oadj = off;     off = align_up(off + (size_t)4 * p->npad * 4, 256);
   p->bytes_fwd = off;
   p->off_sg = off;       off = align_up(off + (size_t)p->grid_b * sg_total(HP, L) * 4, 256);
   p->off_slabs = off;    off = align_up(off + (size_t)(L - 1) * p->groups * HP * HP * 4, 256);
   const size_t ablk = (size_t)HP * (wide ? 64 : PINN_TILE_COLS);
-  p->off_S = off;        off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
-  p->off_Zb = off;       off = align_up(off + (size_t)p->ntiles * L * ablk * 4, 256);
+  // (+1 tile: the pipelined kernels work on PAIRS of tiles; an odd count's dummy partner spills into this scratch block)
+  p->off_S = off;        off = align_up(off + (size_t)(p->ntiles + 1) * L * ablk * 4, 256);
+  p->off_Zb = off;       off = align_up(off + (size_t)(p->ntiles + 1) * L * ablk * 4, 256);
   p->bytes_all = off;
   // Raise the dynamic-LDS limit of the kernels this plan will launch, on the CURRENT device.  It is per-device
   // state of the HIP runtime and idempotent; doing it here, per plan, keeps the launch path free of cached
@@ -191,6 +199,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     BwdArgs ba; memset(&ba, 0, sizeof(ba)); ba.L = L; ba.configure = 1;
     DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1;
     int rc = dispatch_fwd(p, fa, nullptr);
+    if (!rc && p->pipe_f) rc = dispatch_fwd(p, fa, nullptr, true);
     if (!rc) rc = dispatch_bwd(p, ba, nullptr);
     if (!rc) rc = dispatch_dw(p, da, nullptr);
     if (rc) { delete p; return hipfail(rc, "pinn_plan_create(kernel attributes)"); }
@@ -223,10 +232,11 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
-  int rc = dispatch_fwd(plan, a, (hipStream_t)stream);
+  const bool pipe = plan->pipe_f && save;
+  int rc = dispatch_fwd(plan, a, (hipStream_t)stream, pipe);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {
-    rc = launch_loss_sums(a.partials, plan->grid_f, loss_sums, (hipStream_t)stream);
+    rc = launch_loss_sums(a.partials, pipe ? plan->grid_fp : plan->grid_f, loss_sums, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_forward(loss sums)");
   }
   return 0;

@@ -1,0 +1,300 @@
+// Software-pipelined bf16x3 forward sweep for residual mode (4 streams), one wave per SIMD.
+//
+// Same algorithm, same results layout (S, field planes, loss partials) as fwd_bf16.hip - see there and fwd.hip for
+// the reference lines replaced (NSFnet/net.py:52-54, NSFnet/pinn_solver.py:132-163,197-226,
+// ev-NSFnet/pinn_solver.py:290-342,372-428).  What changes is the schedule.  Measured on gfx950 (DESIGN.md section 4,
+// tests/micro/mfma_valu_*.hip, MI355X_MICROARCH.md "Two waves per SIMD"): a SIMD never overlaps one wave's MFMAs with
+// its partner wave's VALU, but inside ONE wave ~24 cycles of vector issue per 32-cycle MFMA are free.  fwd_bf16.hip
+// (8 waves, phases epilogue -> barrier -> GEMM -> barrier in lockstep) therefore pays MFMA time PLUS chain-rule
+// time.  Here a workgroup is HP/64 waves (one per SIMD, 64 features = two 32-row MFMA blocks each, up to 512
+// registers) and keeps TWO tiles (A, B: 32 points x 4 streams each) in flight in opposite phases:
+//
+//     slot:   E0(A) | M1(A)+E0(B) | M1(B)+E1(A) | M2(A)+E1(B) | ... | M_{L-1}(B)+E_{L-1}(A) | E_{L-1}(B) | points
+//
+// M_l(T) = hidden GEMM l of tile T on v_mfma_f32_32x32x16_bf16 (3 MFMAs per product), E_l(T) = tanh chain rule of
+// layer l, hi/lo restage into T's LDS image, S spill.  Inside a slot both are in ONE basic block of the SAME wave,
+// written k-step by k-step with one epilogue slice per k-step, so the chain rule issues in the MFMA shadow.  Each
+// weight fragment streamed from L2 still feeds 12 MFMAs (full 32-point tiles), the accumulators of the two tiles
+// (2 x 128 registers) live in AGPRs/VGPRs of the 512-register budget, the LDS holds two activation images (2 x 64 KB
+// at HP = 256).  The output layer is folded into the last epilogue (partial dot products straight from the
+// registers that hold the a-streams), so the last layer needs no LDS image.
+#include "kernels.h"
+#include "point_stage.h"
+#include "bf16_util.h"
+
+#include <type_traits>
+
+template <int HP>
+struct PipeLds {
+  using XI = XImg<HP, 32>;
+  static constexpr int NW = HP / 64;
+  static constexpr size_t X_BYTES = XI::BYTES;                         // one tile image
+  static constexpr size_t PART_F = (size_t)2 * NW * 12 * 32;           // [tile][wave][3 outputs x 4 streams][32 points]
+  static constexpr size_t OUTV_F = (size_t)2 * 3 * 128;                // [tile][3][128]
+  static size_t bytes(int L) { return 2 * X_BYTES + (PART_F + OUTV_F + (size_t)L * HP + 6 * HP) * sizeof(float); }
+};
+
+template <int HP, int TERMS>
+__global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
+  using G = PipeLds<HP>;
+  using XI = typename G::XI;
+  constexpr int NW = HP / 64, NT = HP, KS = HP / 16, PPL = 32, COLS = 128;
+  constexpr int PRE = 3, RING = 4;      // weight k-steps in flight ahead of their MFMAs (behind the S stores in vmcnt order)
+  constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per S plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* const XA = ldsb;
+  unsigned char* const XB = ldsb + G::X_BYTES;
+  float* const part = reinterpret_cast<float*>(ldsb + 2 * G::X_BYTES);
+  float* const outv = part + G::PART_F;
+  float* const biasL = outv + G::OUTV_F;                  // [L][HP], row 0 = zeros (layer 0's bias is in its pre-activation)
+  float* const woutL = biasL + (size_t)a.L * HP;          // [3][HP]
+  float* const w0L = woutL + 3 * HP;                      // [w0x | w0y | b0][HP]: layer 0 (K = 2) runs on the VALU
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ob0 = w * 64;
+  const float* __restrict__ P = a.prep;
+  const int L = a.L;
+  const int npad = a.ntiles * PPL;
+  float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < L * HP; i += NT) biasL[i] = i < HP ? 0.f : P[prep_b(HP, i / HP) + (i % HP)];
+  for (int i = tid; i < 3 * HP; i += NT) { woutL[i] = P[prep_wout(HP, L) + i]; w0L[i] = P[prep_w0x(HP) + i]; }
+  __syncthreads();
+
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+  // ---- one slot: GEMM `lM` of tile M (accM <- W_lM x image XM) and/or epilogue of layer `lE` of tile E ----
+  // EK: which epilogue - 0 = layer 0 (pre-activations from (x, y) on the VALU, nothing read from accE), 1 = hidden
+  // layer 1..L-2, 2 = last hidden layer (output layer folded in, no LDS image)
+  auto slot = [&](auto DO_M, auto EKIND, f32x16 (&accM)[2][4], const unsigned char* __restrict__ XM, int lM,
+                  f32x16 (&accE)[2][4], unsigned char* __restrict__ XE, int lE, int tileE, float* partE) {
+    constexpr bool doM = decltype(DO_M)::value, doE = true;
+    constexpr int EK = decltype(EKIND)::value;
+    constexpr bool last = EK == 2, first = EK == 0;
+    // lane geometry re-derived per slot from an opaque copy: address arithmetic then lives inside the slot that uses
+    // it instead of being hoisted over all six slot bodies (it was: ~80 long-lived VGPRs, spilled around the loop)
+    int lane_ = lane;
+    asm volatile("" : "+v"(lane_));
+    const int col = lane_ & 31, h = lane_ >> 5, lane = lane_;
+    // ------------- GEMM state -------------
+    u32x4 wh[2][RING], wl[2][RING], bh[2], bo[2];      // B fragments: one column block in use, the next in flight
+    // the wave's fragment slice is a UNIFORM base (scalar registers) + lane * 16 bytes: every load is the
+    // saddr + voffset form, no 64-bit vector address per fragment
+    typedef __attribute__((address_space(1))) u32x4 gu32x4;
+    const gu32x4* const wf = reinterpret_cast<const gu32x4*>(
+        pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, doM ? lM : 1)) + (size_t)(2 * w) * KS * 64));
+    auto wload = [&](int s) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        wh[fb][s % RING] = (wf + (size_t)fb * KS * 64 + s * 64)[lane];
+        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * KS * 64 + s * 64)[lane];
+      }
+    };
+    // B fragments of column block j (= stream j) at k-step s: one conflict-free ds_read_b128 per hi / lo image
+    auto bload = [&](int u) {
+      const int s = u >> 2, j = u & 3;
+      const int off = XI::chunk_off(col, 2 * s + h);
+      bh[u & 1] = *reinterpret_cast<const u32x4*>(XM + j * XI::PLANE * 2 + off);
+      if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(XM + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+    };
+    // step u = (k-step s, column block j): 2 feature blocks x 3 MFMAs on the fragments requested one step earlier
+    auto jstep = [&](int u) {
+      const int s = u >> 2, j = u & 3;
+      if (j == 0 && s + PRE < KS) wload(s + PRE);
+      if (u + 1 < 4 * KS) bload(u + 1);
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        if (s == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          accM[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u & 1], zero) : mfma_bf16(wh[fb][0], bh[u & 1], zero);
+          if (TERMS == 3) {
+            accM[fb][j] = mfma_bf16(wl[fb][0], bh[u & 1], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wh[fb][0], bh[u & 1], accM[fb][j]);
+          }
+        } else {
+          if (TERMS == 3) {
+            accM[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u & 1], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u & 1], accM[fb][j]);
+          }
+          accM[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u & 1], accM[fb][j]);
+        }
+      }
+    };
+    // ------------- epilogue state -------------
+    float* const Sl = a.S + ((size_t)tileE * L + lE) * ((size_t)HP * COLS);
+    const float* const bE = biasL + (size_t)lE * HP;
+    float po[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) po[c][s] = 0.f;
+    f32x4 av[4], sv[4];                   // a-streams / saved streams (t, z_x, z_y, z_D) of the register quad in flight
+    f32x4 b4, wx4, wy4;
+    float px = 0.f, py = 0.f;
+    if (first) {
+      const int pt = tileE * PPL + col;
+      px = pt < a.n ? a.x[pt] : 0.f; py = pt < a.n ? a.y[pt] : 0.f;
+    }
+    // The epilogue of register quad q = (fb, g) (features ob + 8g + 4h + e, this lane's column) in EIGHT slices, one
+    // per 6-MFMA step of the GEMM: slices 0-3 = tanh chain rule of element e, slices 4-7 = plane (stream) p: split
+    // into bf16 hi/lo, restage into XE (or fold into the output layer), spill the saved plane.
+    auto eslice = [&](int q, int i) {
+      const int fb = q >> 2, g = q & 3, ob = ob0 + 32 * fb;
+      if (i < 4) {
+        const int e = i, r = 4 * g + e;
+        float z, zx, zy, zd;
+        if (first) {
+          if (e == 0) {
+            const int o = ob + 8 * g + 4 * h;
+            wx4 = *reinterpret_cast<const f32x4*>(w0L + o); wy4 = *reinterpret_cast<const f32x4*>(w0L + HP + o);
+            b4 = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
+          }
+          z = fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e])); zx = wx4[e]; zy = wy4[e]; zd = 0.f;
+        } else {
+          if (e == 0) b4 = *reinterpret_cast<const f32x4*>(bE + ob + 8 * g + 4 * h);
+          z = accE[fb][0][r] + b4[e]; zx = accE[fb][1][r]; zy = accE[fb][2][r]; zd = accE[fb][3][r];
+        }
+        const float t = fast_tanh(z);
+        const float d1 = 1.f - t * t;
+        const float d2 = -2.f * t * d1;
+        av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
+        sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
+      } else {
+        const int p = i - 4;
+        if (!last) {
+          const int off = XI::chunk_off(col, (ob >> 3) + g) + 8 * h;
+          u32x2 vh, vl;
+          split4(av[p][0], av[p][1], av[p][2], av[p][3], vh, vl);
+          *reinterpret_cast<u32x2*>(XE + p * XI::PLANE * 2 + off) = vh;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(XE + XI::HALF * 2 + p * XI::PLANE * 2 + off) = vl;
+        } else {
+          // output layer (3 x HP, VALU): stream p of this lane's column, this quad's four features
+          const int o = ob + 8 * g + 4 * h;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const f32x4 wo = *reinterpret_cast<const f32x4*>(woutL + c * HP + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) po[c][p] = fmaf(wo[e], av[p][e], po[c][p]);
+          }
+        }
+        const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + col);
+        __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+      }
+    };
+
+    if (doM) {
+#pragma unroll
+      for (int s = 0; s < PRE; ++s) wload(s);
+      bload(0);
+    }
+    // 4 KS steps of 6 MFMAs, each with one epilogue slice in its shadow; nothing crosses a step boundary, so the
+    // requests (weights PRE k-steps ahead, B fragments one step ahead) stay where they are written
+    constexpr int NSTEP = 4 * KS, SPQ = NSTEP / 8;      // steps per register quad (HP = 256: 8 = its 8 slices)
+    static_assert(SPQ == 8 || SPQ == 4, "HP must be 128 or 256");
+#pragma unroll
+    for (int u = 0; u < NSTEP; ++u) {
+      if (doM) jstep(u);
+      if (doE) {
+#pragma unroll
+        for (int i = (u % SPQ) * (8 / SPQ); i < (u % SPQ + 1) * (8 / SPQ); ++i) eslice(u / SPQ, i);
+      }
+      if (doM && doE) {
+#pragma unroll
+        for (int i = 0; i < (TERMS == 3 ? 6 : 2); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 8, 0);   // epilogue VALU in its shadow
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (doE && last) {
+      // the lane pair (l, l + 32) holds the same column: add the halves, half 0 publishes the wave's partial sums
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          partE[(w * 12 + c * 4 + s) * 32 + col] = po[c][s] + __shfl_xor(po[c][s], 32, 64);   // (both halves: same value)
+        }
+    }
+  };
+
+  // ---- output-layer bias + cross-wave sum, then the per-point residual / loss stage (point_stage.h) ----
+  auto points = [&](int tile, const float* partT, float* outvT) {
+    for (int idx = tid; idx < 3 * COLS; idx += NT) {
+      const int c3 = idx / COLS, cc = idx % COLS;
+      float s = cc < PPL ? P[prep_bout(HP, L) + c3] : 0.f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww) s += partT[(ww * 12 + c3 * 4 + cc / PPL) * 32 + (cc % PPL)];
+      outvT[c3 * COLS + cc] = s;
+    }
+  };
+
+  const int npairs = (a.ntiles + 1) / 2;
+  float* const partA = part, *const partB = part + (size_t)NW * 12 * 32;
+  float* const outvA = outv, *const outvB = outv + 3 * 128;
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+    const int tA = 2 * pair, tB = 2 * pair + 1;      // tB == ntiles: a dummy tile (masked points, scratch S block)
+    f32x16 accA[2][4], accB[2][4];
+    slot(F_{}, K0{}, accB, XB, 1, accA, XA, 0, tA, partA);                      //            E_0(A)
+    __syncthreads();
+    slot(T_{}, K0{}, accA, XA, 1, accB, XB, 0, tB, partB);                      // M_1(A)   + E_0(B)
+    __syncthreads();
+    for (int l = 1; l < L - 1; ++l) {
+      slot(T_{}, K1{}, accB, XB, l, accA, XA, l, tA, partA);                    // M_l(B)   + E_l(A)
+      __syncthreads();
+      slot(T_{}, K1{}, accA, XA, l + 1, accB, XB, l, tB, partB);                // M_l+1(A) + E_l(B)
+      __syncthreads();
+    }
+    slot(T_{}, K2{}, accB, XB, L - 1, accA, XA, L - 1, tA, partA);              // M_L-1(B) + E_L-1(A), output layer
+    __syncthreads();
+    slot(F_{}, K2{}, accA, XA, 1, accB, XB, L - 1, tB, partB);                  //            E_L-1(B)
+    __syncthreads();
+    points(tA, partA, outvA);
+    points(tB, partB, outvB);
+    __syncthreads();
+    residual_point_stage<PPL, COLS>(a, outvA, tA, tid, npad, lsum);
+    if (tB < a.ntiles) residual_point_stage<PPL, COLS>(a, outvB, tB, tid, npad, lsum);
+    __syncthreads();
+  }
+  float* red = reinterpret_cast<float*>(ldsb);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k * NT + tid] = lsum[k];
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.f;
+    for (int t = 0; t < NT; ++t) s += red[tid * NT + t];
+    a.partials[blockIdx.x * PINN_NLOSS + tid] = s;
+  } else if (tid < PINN_NLOSS) {
+    a.partials[blockIdx.x * PINN_NLOSS + tid] = 0.f;
+  }
+}
+
+size_t fwd_pipe_lds_bytes(int HP, int L) {
+  switch (HP) {
+    case 128: return PipeLds<128>::bytes(L);
+    case 192: return PipeLds<192>::bytes(L);
+    default: return PipeLds<256>::bytes(L);
+  }
+}
+
+template <int HP, int TERMS>
+static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
+  const size_t lds = PipeLds<HP>::bytes(a.L);
+  if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_pipe_kernel<HP, TERMS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return e == hipSuccess ? 0 : -(int)e;
+  }
+  hipLaunchKernelGGL((fwd_pipe_kernel<HP, TERMS>), dim3(grid), dim3(HP), lds, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// residual mode, saved activations, L >= 2 hidden layers, HP = 256 (the caller checks)
+int launch_fwd_pipe(int HP, int terms, const FwdArgs& a, int grid, hipStream_t s) {
+  if (HP != 256) return -1000;
+  return terms == 3 ? launch_one<256, 3>(a, grid, s) : launch_one<256, 1>(a, grid, s);
+}

@@ -1,0 +1,71 @@
+"""The software-pipelined (one wave per SIMD, two tiles in flight) bf16 kernels against the 8-wave kernels they
+replace for hidden = 256 and against the fp64 oracle: same fields, loss sums, saved activations (seen through the
+gradient the reverse sweep computes from them) for even / odd / single tile counts, ragged point counts, 2..7 hidden
+layers, both bf16 modes, plain and ev flavour.  The two schedules sum in a different order (bias added after the
+GEMM instead of seeding it), so they agree to fp32 rounding, not bit for bit: tolerance 2e-6 of the field's max."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import autograd_ref as ar
+from oracle import fwdmode_ref as fr
+
+pytestmark = pytest.mark.gpu
+H = 256
+
+
+def _run(monkeypatch, pipe, L, N, prec, ev=False):
+    from nsfnet_amd import engine as eng
+    monkeypatch.setenv("PINN_PIPE", "1" if pipe else "0")
+    dev = torch.device("cuda:0")
+    flat = ar.flat_params(ar.seeded_net(3, L, H, seed=40 + L)).numpy().copy()
+    rng = np.random.RandomState(N)
+    x = rng.rand(N).astype(np.float32); y = rng.rand(N).astype(np.float32)
+    xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+    kw = dict(flavour="ev", n_hidden_e=2, hidden_e=24, alpha_evm=0.05) if ev else {}
+    E = eng.PinnEngine(dev, L, H, 1500.0, alpha_b=10.0, alpha_e=1.0, precision=prec, **kw)
+    E.net.set_flat(torch.tensor(flat))
+    if ev:
+        E.net_e.set_flat(ar.flat_params(ar.seeded_net(1, 2, 24, seed=3)))
+        E.e_trainable = True
+    E.set_collocation(x, y, weights=(0.5 + rng.rand(N)).astype(np.float32) if ev else None)
+    E.set_boundary(xb, yb, ub, vb)
+    E.loss_and_grad()
+    torch.cuda.synchronize()
+    out = dict(fields=E.plan_f.fields[:, :N].cpu().numpy().astype(np.float64), sums=E.sums.cpu().numpy().astype(np.float64),
+               grads=E.grads.cpu().numpy().astype(np.float64), flat=flat, x=x, y=y,
+               vis=E.plan_f.vis_t.cpu().numpy().copy())
+    if ev:
+        out["grads_e"] = E.grads_e.cpu().numpy().astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("L,N", [(6, 320), (6, 330), (6, 20), (2, 97), (3, 640), (7, 65), (4, 2049)])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_pipelined_forward_matches_8wave_kernels(monkeypatch, L, N, prec):
+    a = _run(monkeypatch, True, L, N, prec)
+    b = _run(monkeypatch, False, L, N, prec)
+    tol = 2e-6 if prec == "bf16x3" else 2e-2        # plain bf16: operands rounded to 8 bits, order effects are visible
+    for k in range(a["fields"].shape[0]):
+        scale = max(np.abs(b["fields"][k]).max(), 1e-30)
+        assert np.abs(a["fields"][k] - b["fields"][k]).max() <= tol * scale, k
+    np.testing.assert_allclose(a["sums"][:4], b["sums"][:4], rtol=10 * tol, atol=1e-30)
+    assert np.linalg.norm(a["grads"] - b["grads"]) <= 10 * tol * np.linalg.norm(b["grads"])
+    if prec == "bf16x3":      # and against the fp64 oracle at the bf16x3 bars
+        P = fr.unflatten(a["flat"].astype(np.float64), 2, 3, L, H)
+        r = fr.pde_loss_and_grad(P, a["x"].astype(np.float64), a["y"].astype(np.float64), 1500.0, alpha_e=1.0)
+        for k, name in ((6, "eq1"), (7, "eq2"), (8, "eq3")):
+            assert np.abs(a["fields"][k] - r["eqs"][k - 6]).max() < 5e-4 * np.abs(r["eqs"][k - 6]).max(), name
+        np.testing.assert_allclose(a["sums"][:3], r["sums"], rtol=2e-4)
+
+
+def test_pipelined_forward_ev_flavour(monkeypatch):
+    a = _run(monkeypatch, True, 5, 450, "bf16x3", ev=True)
+    b = _run(monkeypatch, False, 5, 450, "bf16x3", ev=True)
+    for k in range(a["fields"].shape[0]):
+        scale = max(np.abs(b["fields"][k]).max(), 1e-30)
+        assert np.abs(a["fields"][k] - b["fields"][k]).max() <= 2e-6 * scale, k
+    np.testing.assert_array_equal(a["vis"], b["vis"])
+    np.testing.assert_allclose(a["sums"][:4], b["sums"][:4], rtol=2e-5)
+    assert np.linalg.norm(a["grads"] - b["grads"]) <= 2e-5 * np.linalg.norm(b["grads"])
+    assert np.linalg.norm(a["grads_e"] - b["grads_e"]) <= 2e-5 * np.linalg.norm(b["grads_e"])
