@@ -83,9 +83,11 @@ def test_ev_nsfnet_is_class2_and_plain_nsfnet_a_different_closed_vortex(monkeypa
     P = ps.PysicsInformedNeuralNetwork(Re=2000, layers=4, hidden_size=120, N_f=66049, bc_weight=10, eq_weight=1,
                                        net_params=net)
     P.set_boundary_data(X=ar.cavity_boundary())
-    P.set_eq_training_data(X=(X.reshape(-1, 1), Y.reshape(-1, 1)))          # residuals on the whole DNS grid, not the training set
+    rng = np.random.RandomState(2024)                                      # residuals on FRESH interior points, not the training set
+    P.set_eq_training_data(X=(rng.rand(60000, 1), rng.rand(60000, 1)))
     loss, (loss_e, loss_b) = P.fwd_computing_loss_2d()
-    assert float(P.loss_eq1) < 1e-5 and float(P.loss_eq2) < 1e-5 and float(P.loss_eq3) < 1e-5      # a Navier-Stokes solution
+    res = [float(P.loss_eq1), float(P.loss_eq2), float(P.loss_eq3)]
+    assert max(res) < 1e-5, res                                                                    # a Navier-Stokes solution
     assert float(loss_b) < 1e-6 and c1["mass_defect"] < 2e-3                                       # of the same BVP
     assert c1["primary"]["psi_min"] < -0.05                                                        # one strong closed vortex
     assert np.hypot(c1["primary"]["x"] - dns["primary"]["x"], c1["primary"]["y"] - dns["primary"]["y"]) > 0.1   # elsewhere
