@@ -189,19 +189,14 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
           const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + col);
           __builtin_nontemporal_store(zq[p], pin_base(reinterpret_cast<const f32x4*>(Zl) + p * PLQ) + so);
         }
-        // column sums of the four features at once (reduce_util.h); lane col == e of each half commits feature e
+        // column sums of the four features at once (reduce_util.h); lane col == e of each half commits feature e.
+        // One sum per slice: db in slice 4; dW_out (first kind) / dW_0 (last kind) in slices 5-7.
         if (p == 0) commit(sg_db(HP, lE), q, sum_cols4<32>(zq[0][0], zq[0][1], zq[0][2], zq[0][3], lane));
-        if (first) commit(sg_wout(HP, L) + (p == 0 ? 0 : 0), q, 0.f), (void)0;
+        if (first && p >= 1)
+          commit(sg_wout(HP, L) + (p - 1) * HP, q, sum_cols4<32>(wov[(p + 2) % 3][0], wov[(p + 2) % 3][1], wov[(p + 2) % 3][2], wov[(p + 2) % 3][3], lane));
+        if (last && (p == 1 || p == 2))
+          commit(p == 1 ? sg_w0x(HP, L) : sg_w0y(HP, L), q, sum_cols4<32>(dwv[(p + 1) % 2][0], dwv[(p + 1) % 2][1], dwv[(p + 1) % 2][2], dwv[(p + 1) % 2][3], lane));
       }
-    };
-    (void)eslice;
-    // (the first-kind dW_out sums and the last-kind dW_0 sums are committed in slices 5-7: see eslice2 below)
-    auto eslice2 = [&](int q, int i) {
-      if (i < 5) return;
-      const int p = i - 4;      // 1..3
-      if (first) commit(sg_wout(HP, L) + (p - 1) * HP, q, sum_cols4<32>(wov[p - 1][0], wov[p - 1][1], wov[p - 1][2], wov[p - 1][3], lane));
-      if (last && p <= 2) commit(p == 1 ? sg_w0x(HP, L) : sg_w0y(HP, L), q,
-                                 sum_cols4<32>(dwv[p - 1][0], dwv[p - 1][1], dwv[p - 1][2], dwv[p - 1][3], lane));
     };
 
     if (doM) {
@@ -216,7 +211,6 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
     for (int u = 0; u < NSTEP; ++u) {
       if (doM) jstep(u);
       eslice(u / SPQ, u % SPQ);
-      eslice2(u / SPQ, u % SPQ);
       if (doM) {
 #pragma unroll
         for (int i = 0; i < (TERMS == 3 ? 6 : 2); ++i) {

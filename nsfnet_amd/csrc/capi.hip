@@ -168,6 +168,10 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   p->pipe_f = net->prec_fwd != 0 && HP == 256 && !wide && streams == 4 && L >= 2 && env_int("PINN_PIPE", 1) != 0 &&
               fwd_pipe_lds_bytes(HP, L) <= 163840;
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
+  if (env_int("PINN_VERBOSE", 0))
+    fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, pipelined fwd %d (lds %zu)\n",
+            (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f,
+            fwd_pipe_lds_bytes(HP, L));
   p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
   if (L > 1) {

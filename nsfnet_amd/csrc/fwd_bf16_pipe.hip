@@ -6,18 +6,24 @@
 // tests/micro/mfma_valu_*.hip, MI355X_MICROARCH.md "Two waves per SIMD"): a SIMD never overlaps one wave's MFMAs with
 // its partner wave's VALU, but inside ONE wave ~24 cycles of vector issue per 32-cycle MFMA are free.  fwd_bf16.hip
 // (8 waves, phases epilogue -> barrier -> GEMM -> barrier in lockstep) therefore pays MFMA time PLUS chain-rule
-// time.  Here a workgroup is HP/64 waves (one per SIMD, 64 features = two 32-row MFMA blocks each, up to 512
-// registers) and keeps TWO tiles (A, B: 32 points x 4 streams each) in flight in opposite phases:
+// time.  Here a workgroup is HP/64 = 4 waves (one per SIMD, two 32-row MFMA blocks each, up to 512 registers) and
+// keeps TWO tiles (A, B: 32 points x 4 streams each) in flight in opposite phases:
 //
 //     slot:   E0(A) | M1(A)+E0(B) | M1(B)+E1(A) | M2(A)+E1(B) | ... | M_{L-1}(B)+E_{L-1}(A) | E_{L-1}(B) | points
 //
 // M_l(T) = hidden GEMM l of tile T on v_mfma_f32_32x32x16_bf16 (3 MFMAs per product), E_l(T) = tanh chain rule of
-// layer l, hi/lo restage into T's LDS image, S spill.  Inside a slot both are in ONE basic block of the SAME wave,
-// written k-step by k-step with one epilogue slice per k-step, so the chain rule issues in the MFMA shadow.  Each
-// weight fragment streamed from L2 still feeds 12 MFMAs (full 32-point tiles), the accumulators of the two tiles
-// (2 x 128 registers) live in AGPRs/VGPRs of the 512-register budget, the LDS holds two activation images (2 x 64 KB
-// at HP = 256).  The output layer is folded into the last epilogue (partial dot products straight from the
-// registers that hold the a-streams), so the last layer needs no LDS image.
+// layer l, hi/lo split, S spill.  Inside a slot both are in ONE basic block of the SAME wave, six MFMAs and one
+// epilogue slice per step, so the chain rule issues in the MFMA shadow; every weight fragment streamed from L2 still
+// feeds 12 MFMAs (full 32-point tiles).
+//
+// One tile's bf16 hi/lo image is 128 KB at HP = 256, so two images do not fit the 160 KB of LDS.  The two tiles SHARE
+// one image, split along K: R1 = features 0..HP/2-1, R2 = the rest.  Wave w owns the 32-row blocks w (in R1) and
+// NW + w (in R2).  A slot is two sub-slots with a barrier between them: in sub-slot 1 the GEMM reads R1 and the
+// epilogue computes its R1 block, in sub-slot 2 the GEMM reads R2 and the epilogue computes its R2 block.  What an
+// epilogue produces is parked in 64 registers and written into the image half the GEMM has just finished with, half
+// a slot later (R1 data during sub-slot 2, R2 data during sub-slot 1 of the next slot), one register quad per step.
+// The output layer is folded into the last epilogue (partial dot products straight from the registers), so the last
+// layer needs no image.
 #include "kernels.h"
 #include "point_stage.h"
 #include "bf16_util.h"
@@ -28,10 +34,10 @@ template <int HP>
 struct PipeLds {
   using XI = XImg<HP, 32>;
   static constexpr int NW = HP / 64;
-  static constexpr size_t X_BYTES = XI::BYTES;                         // one tile image
+  static constexpr size_t X_BYTES = XI::BYTES;                         // THE tile image (shared by the two tiles)
   static constexpr size_t PART_F = (size_t)2 * NW * 12 * 32;           // [tile][wave][3 outputs x 4 streams][32 points]
   static constexpr size_t OUTV_F = (size_t)2 * 3 * 128;                // [tile][3][128]
-  static size_t bytes(int L) { return 2 * X_BYTES + (PART_F + OUTV_F + (size_t)L * HP + 6 * HP) * sizeof(float); }
+  static size_t bytes(int L) { return X_BYTES + (PART_F + OUTV_F + (size_t)L * HP + 6 * HP) * sizeof(float); }
 };
 
 template <int HP, int TERMS>
@@ -42,16 +48,14 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   constexpr int PRE = 3, RING = 4;      // weight k-steps in flight ahead of their MFMAs (behind the S stores in vmcnt order)
   constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per S plane
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char* const XA = ldsb;
-  unsigned char* const XB = ldsb + G::X_BYTES;
-  float* const part = reinterpret_cast<float*>(ldsb + 2 * G::X_BYTES);
+  unsigned char* const X = ldsb;
+  float* const part = reinterpret_cast<float*>(ldsb + G::X_BYTES);
   float* const outv = part + G::PART_F;
   float* const biasL = outv + G::OUTV_F;                  // [L][HP], row 0 = zeros (layer 0's bias is in its pre-activation)
   float* const woutL = biasL + (size_t)a.L * HP;          // [3][HP]
   float* const w0L = woutL + 3 * HP;                      // [w0x | w0y | b0][HP]: layer 0 (K = 2) runs on the VALU
-  const int tid = threadIdx.x, lane = tid & 63, col = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ob0 = w * 64;
   const float* __restrict__ P = a.prep;
   const int L = a.L;
   const int npad = a.ntiles * PPL;
@@ -63,45 +67,50 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   using T_ = std::true_type;
   using F_ = std::false_type;
 
-  // ---- one slot: GEMM `lM` of tile M (accM <- W_lM x image XM) and/or epilogue of layer `lE` of tile E ----
-  // EK: which epilogue - 0 = layer 0 (pre-activations from (x, y) on the VALU, nothing read from accE), 1 = hidden
-  // layer 1..L-2, 2 = last hidden layer (output layer folded in, no LDS image)
-  auto slot = [&](auto DO_M, auto EKIND, f32x16 (&accM)[2][4], const unsigned char* __restrict__ XM, int lM,
-                  f32x16 (&accE)[2][4], unsigned char* __restrict__ XE, int lE, int tileE, float* partE) {
-    constexpr bool doM = decltype(DO_M)::value, doE = true;
+  // parked epilogue output: [register quad g of the block][stream p][hi | lo], 4 bf16 each.  Lives across slots.
+  u32x2 st[4][4][2];
+
+  // ---- one slot: GEMM `lM` of tile M (accM <- W_lM x image) and the epilogue of layer `lE` of tile E ----
+  // EK: 0 = layer 0 (pre-activations from (x, y) on the VALU, nothing read from accE), 1 = hidden layer 1..L-2,
+  //     2 = last hidden layer (output layer folded in, nothing parked).  DUMP1: the parked registers hold the R2 block
+  //     of the previous slot's epilogue (to be written during sub-slot 1).
+  auto slot = [&](auto DO_M, auto EKIND, auto DUMP1_, f32x16 (&accM)[2][4], int lM, f32x16 (&accE)[2][4], int lE,
+                  int tileE, float* partE) {
+    constexpr bool doM = decltype(DO_M)::value, dump1 = decltype(DUMP1_)::value;
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool last = EK == 2, first = EK == 0;
     // lane geometry re-derived per slot from an opaque copy: address arithmetic then lives inside the slot that uses
-    // it instead of being hoisted over all six slot bodies (it was: ~80 long-lived VGPRs, spilled around the loop)
+    // it instead of being hoisted over all slot bodies (it was: ~80 long-lived VGPRs, spilled around the layer loop)
     int lane_ = lane;
     asm volatile("" : "+v"(lane_));
-    const int col = lane_ & 31, h = lane_ >> 5, lane = lane_;
+    const int col = lane_ & 31, h = lane_ >> 5;
     // ------------- GEMM state -------------
     u32x4 wh[2][RING], wl[2][RING], bh[2], bo[2];      // B fragments: one column block in use, the next in flight
-    // the wave's fragment slice is a UNIFORM base (scalar registers) + lane * 16 bytes: every load is the
-    // saddr + voffset form, no 64-bit vector address per fragment
+    // the wave's fragment slices are UNIFORM bases (scalar registers) + lane * 16 bytes: every load is the
+    // saddr + voffset form, no 64-bit vector address per fragment.  Row block of (wave, fb) = fb * NW + w.
     typedef __attribute__((address_space(1))) u32x4 gu32x4;
     const gu32x4* const wf = reinterpret_cast<const gu32x4*>(
-        pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, doM ? lM : 1)) + (size_t)(2 * w) * KS * 64));
+        pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, doM ? lM : 1)) + (size_t)w * KS * 64));
     auto wload = [&](int s) {
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
-        wh[fb][s % RING] = (wf + (size_t)fb * KS * 64 + s * 64)[lane];
-        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * KS * 64 + s * 64)[lane];
+        wh[fb][s % RING] = (wf + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
+        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
       }
     };
     // B fragments of column block j (= stream j) at k-step s: one conflict-free ds_read_b128 per hi / lo image
     auto bload = [&](int u) {
       const int s = u >> 2, j = u & 3;
       const int off = XI::chunk_off(col, 2 * s + h);
-      bh[u & 1] = *reinterpret_cast<const u32x4*>(XM + j * XI::PLANE * 2 + off);
-      if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(XM + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+      bh[u & 1] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
+      if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
     };
     // step u = (k-step s, column block j): 2 feature blocks x 3 MFMAs on the fragments requested one step earlier
+    // (the request for the first step of sub-slot 2 is made after the mid-slot barrier, not here)
     auto jstep = [&](int u) {
       const int s = u >> 2, j = u & 3;
       if (j == 0 && s + PRE < KS) wload(s + PRE);
-      if (u + 1 < 4 * KS) bload(u + 1);
+      if (u + 1 < 4 * KS && u + 1 != 2 * KS) bload(u + 1);
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
         if (s == 0) {
@@ -136,10 +145,11 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
       px = pt < a.n ? a.x[pt] : 0.f; py = pt < a.n ? a.y[pt] : 0.f;
     }
     // The epilogue of register quad q = (fb, g) (features ob + 8g + 4h + e, this lane's column) in EIGHT slices, one
-    // per 6-MFMA step of the GEMM: slices 0-3 = tanh chain rule of element e, slices 4-7 = plane (stream) p: split
-    // into bf16 hi/lo, restage into XE (or fold into the output layer), spill the saved plane.
+    // per 6-MFMA step of the GEMM: slices 0-3 = tanh chain rule of element e, slices 4-7 = plane (stream) p: write
+    // the parked quad (g, p) of the OTHER block into the image half the GEMM is not reading, split the new values
+    // into bf16 hi/lo and park them (or fold them into the output layer), spill the saved plane.
     auto eslice = [&](int q, int i) {
-      const int fb = q >> 2, g = q & 3, ob = ob0 + 32 * fb;
+      const int fb = q >> 2, g = q & 3, ob = 32 * (fb * NW + w);
       if (i < 4) {
         const int e = i, r = 4 * g + e;
         float z, zx, zy, zd;
@@ -161,12 +171,16 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
         sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
       } else {
         const int p = i - 4;
+        if (fb == 0 ? dump1 : !last) {
+          // parked quad (g, p) of the other block: R2 data of the previous slot while R1 is read, R1 data of this
+          // slot while R2 is read
+          const int obo = 32 * ((1 - fb) * NW + w);
+          const int off = XI::chunk_off(col, (obo >> 3) + g) + 8 * h;
+          *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = st[g][p][0];
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = st[g][p][1];
+        }
         if (!last) {
-          const int off = XI::chunk_off(col, (ob >> 3) + g) + 8 * h;
-          u32x2 vh, vl;
-          split4(av[p][0], av[p][1], av[p][2], av[p][3], vh, vl);
-          *reinterpret_cast<u32x2*>(XE + p * XI::PLANE * 2 + off) = vh;
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(XE + XI::HALF * 2 + p * XI::PLANE * 2 + off) = vl;
+          split4(av[p][0], av[p][1], av[p][2], av[p][3], st[g][p][0], st[g][p][1]);
         } else {
           // output layer (3 x HP, VALU): stream p of this lane's column, this quad's four features
           const int o = ob + 8 * g + 4 * h;
@@ -189,16 +203,17 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
     }
     // 4 KS steps of 6 MFMAs, each with one epilogue slice in its shadow; nothing crosses a step boundary, so the
     // requests (weights PRE k-steps ahead, B fragments one step ahead) stay where they are written
-    constexpr int NSTEP = 4 * KS, SPQ = NSTEP / 8;      // steps per register quad (HP = 256: 8 = its 8 slices)
-    static_assert(SPQ == 8 || SPQ == 4, "HP must be 128 or 256");
+    constexpr int NSTEP = 4 * KS;
+    static_assert(NSTEP == 64, "HP must be 256 (8 steps per register quad, 4 quads per sub-slot)");
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
-      if (doM) jstep(u);
-      if (doE) {
-#pragma unroll
-        for (int i = (u % SPQ) * (8 / SPQ); i < (u % SPQ + 1) * (8 / SPQ); ++i) eslice(u / SPQ, i);
+      if (u == NSTEP / 2) {
+        __syncthreads();                  // R1 has been read by every wave, R2 is complete
+        if (doM) bload(u);
       }
-      if (doM && doE) {
+      if (doM) jstep(u);
+      eslice(u / 8, u % 8);
+      if (doM) {
 #pragma unroll
         for (int i = 0; i < (TERMS == 3 ? 6 : 2); ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
@@ -207,14 +222,13 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (doE && last) {
-      // the lane pair (l, l + 32) holds the same column: add the halves, half 0 publishes the wave's partial sums
+    if (last) {
+      // the lane pair (l, l + 32) holds the same column: add the halves (both publish the same value)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          partE[(w * 12 + c * 4 + s) * 32 + col] = po[c][s] + __shfl_xor(po[c][s], 32, 64);   // (both halves: same value)
-        }
+        for (int s = 0; s < 4; ++s)
+          partE[(w * 12 + c * 4 + s) * 32 + col] = po[c][s] + __shfl_xor(po[c][s], 32, 64);
     }
   };
 
@@ -238,19 +252,19 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
     const int tA = 2 * pair, tB = 2 * pair + 1;      // tB == ntiles: a dummy tile (masked points, scratch S block)
     f32x16 accA[2][4], accB[2][4];
-    slot(F_{}, K0{}, accB, XB, 1, accA, XA, 0, tA, partA);                      //            E_0(A)
+    slot(F_{}, K0{}, F_{}, accB, 1, accA, 0, tA, partA);                        //            E_0(A)
     __syncthreads();
-    slot(T_{}, K0{}, accA, XA, 1, accB, XB, 0, tB, partB);                      // M_1(A)   + E_0(B)
+    slot(T_{}, K0{}, T_{}, accA, 1, accB, 0, tB, partB);                        // M_1(A)   + E_0(B)
     __syncthreads();
     for (int l = 1; l < L - 1; ++l) {
-      slot(T_{}, K1{}, accB, XB, l, accA, XA, l, tA, partA);                    // M_l(B)   + E_l(A)
+      slot(T_{}, K1{}, T_{}, accB, l, accA, l, tA, partA);                      // M_l(B)   + E_l(A)
       __syncthreads();
-      slot(T_{}, K1{}, accA, XA, l + 1, accB, XB, l, tB, partB);                // M_l+1(A) + E_l(B)
+      slot(T_{}, K1{}, T_{}, accA, l + 1, accB, l, tB, partB);                  // M_l+1(A) + E_l(B)
       __syncthreads();
     }
-    slot(T_{}, K2{}, accB, XB, L - 1, accA, XA, L - 1, tA, partA);              // M_L-1(B) + E_L-1(A), output layer
+    slot(T_{}, K2{}, T_{}, accB, L - 1, accA, L - 1, tA, partA);                // M_L-1(B) + E_L-1(A), output layer
     __syncthreads();
-    slot(F_{}, K2{}, accA, XA, 1, accB, XB, L - 1, tB, partB);                  //            E_L-1(B)
+    slot(F_{}, K2{}, F_{}, accA, 1, accB, L - 1, tB, partB);                    //            E_L-1(B)
     __syncthreads();
     points(tA, partA, outvA);
     points(tB, partB, outvB);
@@ -272,13 +286,7 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   }
 }
 
-size_t fwd_pipe_lds_bytes(int HP, int L) {
-  switch (HP) {
-    case 128: return PipeLds<128>::bytes(L);
-    case 192: return PipeLds<192>::bytes(L);
-    default: return PipeLds<256>::bytes(L);
-  }
-}
+size_t fwd_pipe_lds_bytes(int HP, int L) { (void)HP; return PipeLds<256>::bytes(L); }
 
 template <int HP, int TERMS>
 static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
