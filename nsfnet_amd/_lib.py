@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnsfnet_pinn.so")
+# $NSFNET_PINN_LIB selects another build of the same ABI (kernel experiments: scripts/abl_build.py)
+LIB_PATH = os.environ.get("NSFNET_PINN_LIB") or os.path.join(_HERE, "lib", "libnsfnet_pinn.so")
 
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 

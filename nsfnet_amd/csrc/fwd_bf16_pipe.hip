@@ -30,6 +30,22 @@
 
 #include <type_traits>
 
+// timing-only ablation switches (scripts/abl_build.py builds variant libraries; never set in the product build):
+// 1 = no S spill, 2 = weight fragments loaded once per slot, 4 = no epilogue arithmetic, 8 = no mid-slot barrier,
+// 16 = no parked-quad writes into the image, 32 = no B-fragment LDS reads after the first
+#ifndef PINN_ABL
+#define PINN_ABL 0
+#endif
+
+// Just-in-time AGPR -> VGPR read of one accumulator element.  The two tiles' accumulators fill the 256 AccVGPRs; the
+// epilogue's VALU cannot read those directly.  Left to itself the register allocator copies a whole 128-register
+// accumulator set into VGPRs at the top of the slot (and spills around it); the asm pins each read to its use.
+__device__ __forceinline__ float acc_read(float acc_elem) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_elem));
+  return v;
+}
+
 template <int HP>
 struct PipeLds {
   using XI = XImg<HP, 32>;
@@ -45,7 +61,14 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   using G = PipeLds<HP>;
   using XI = typename G::XI;
   constexpr int NW = HP / 64, NT = HP, KS = HP / 16, PPL = 32, COLS = 128;
-  constexpr int PRE = 3, RING = 4;      // weight k-steps in flight ahead of their MFMAs (behind the S stores in vmcnt order)
+#ifndef PINN_PRE
+#define PINN_PRE 1
+#endif
+  constexpr int PRE = PINN_PRE, RING = PRE + 1;      // weight k-steps in flight ahead of their MFMAs (behind the S stores in vmcnt order)
+#ifndef PINN_BD
+#define PINN_BD 1
+#endif
+  constexpr int BD = PINN_BD;           // B-fragment (LDS) requests in flight ahead of their MFMAs, in 6-MFMA steps
   constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per S plane
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* const X = ldsb;
@@ -66,16 +89,29 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
 
   using T_ = std::true_type;
   using F_ = std::false_type;
+#ifdef PINN_STAMP
+  // diagnostic build only: s_memtime stamps of workgroup 0 (first pair of tiles) into the buffer passed as `e`
+  long long* const stamp = reinterpret_cast<long long*>(const_cast<float*>(a.e)) + w * 64;
+  int nstamp = 0;
+#define STAMP() do { if (blockIdx.x == 0 && nstamp < 64) { stamp[nstamp] = __builtin_amdgcn_s_memtime(); } ++nstamp; } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
 
   // parked epilogue output: [register quad g of the block][stream p][hi | lo], 4 bf16 each.  Lives across slots.
   u32x2 st[4][4][2];
+  // weight-fragment ring [feature block][k-step % RING]: lives across slots, because the first PRE k-steps of the
+  // NEXT slot's GEMM are requested during the last k-steps of this one (a load issued right after the barrier would
+  // expose the L2 latency and, vmcnt being in order, the drain of every S store issued before it)
+  u32x4 wh[2][RING], wl[2][RING];
 
   // ---- one slot: GEMM `lM` of tile M (accM <- W_lM x image) and the epilogue of layer `lE` of tile E ----
   // EK: 0 = layer 0 (pre-activations from (x, y) on the VALU, nothing read from accE), 1 = hidden layer 1..L-2,
   //     2 = last hidden layer (output layer folded in, nothing parked).  DUMP1: the parked registers hold the R2 block
   //     of the previous slot's epilogue (to be written during sub-slot 1).
-  auto slot = [&](auto DO_M, auto EKIND, auto DUMP1_, f32x16 (&accM)[2][4], int lM, f32x16 (&accE)[2][4], int lE,
-                  int tileE, float* partE) {
+  // lNext: layer of the NEXT slot's GEMM (0: the next slot has none)
+  auto slot = [&](auto DO_M, auto EKIND, auto DUMP1_, f32x16 (&accM)[2][4], int lM, int lNext, f32x16 (&accE)[2][4],
+                  int lE, int tileE, float* partE) {
     constexpr bool doM = decltype(DO_M)::value, dump1 = decltype(DUMP1_)::value;
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool last = EK == 2, first = EK == 0;
@@ -85,47 +121,53 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
     asm volatile("" : "+v"(lane_));
     const int col = lane_ & 31, h = lane_ >> 5;
     // ------------- GEMM state -------------
-    u32x4 wh[2][RING], wl[2][RING], bh[2], bo[2];      // B fragments: one column block in use, the next in flight
+    u32x4 bh[BD + 1], bo[BD + 1];      // B fragments: one column block in use, BD in flight
     // the wave's fragment slices are UNIFORM bases (scalar registers) + lane * 16 bytes: every load is the
     // saddr + voffset form, no 64-bit vector address per fragment.  Row block of (wave, fb) = fb * NW + w.
     typedef __attribute__((address_space(1))) u32x4 gu32x4;
     const gu32x4* const wf = reinterpret_cast<const gu32x4*>(
         pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, doM ? lM : 1)) + (size_t)w * KS * 64));
-    auto wload = [&](int s) {
+    const gu32x4* const wfn = reinterpret_cast<const gu32x4*>(
+        pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, lNext > 0 ? lNext : 1)) + (size_t)w * KS * 64));
+    static_assert(KS % RING == 0, "the ring index of k-step s of the next slot must be s % RING");
+    auto wload = [&](const gu32x4* base, int s) {
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
-        wh[fb][s % RING] = (wf + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
-        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
+        wh[fb][s % RING] = (base + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
+        if (TERMS == 3) wl[fb][s % RING] = (base + (size_t)(HP * HP / 8) + (size_t)fb * NW * KS * 64 + s * 64)[lane_];
       }
     };
     // B fragments of column block j (= stream j) at k-step s: one conflict-free ds_read_b128 per hi / lo image
     auto bload = [&](int u) {
       const int s = u >> 2, j = u & 3;
       const int off = XI::chunk_off(col, 2 * s + h);
-      bh[u & 1] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
-      if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+      bh[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
+      if (TERMS == 3) bo[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
     };
-    // step u = (k-step s, column block j): 2 feature blocks x 3 MFMAs on the fragments requested one step earlier
-    // (the request for the first step of sub-slot 2 is made after the mid-slot barrier, not here)
+    // step u = (k-step s, column block j): 2 feature blocks x 3 MFMAs on the fragments requested BD steps earlier
+    // (the requests for the first BD steps of sub-slot 2 are made after the mid-slot barrier, not here)
     auto jstep = [&](int u) {
       const int s = u >> 2, j = u & 3;
-      if (j == 0 && s + PRE < KS) wload(s + PRE);
-      if (u + 1 < 4 * KS && u + 1 != 2 * KS) bload(u + 1);
+      if (j == 0 && !(PINN_ABL & 2)) {
+        if (s + PRE < KS) wload(wf, s + PRE);
+        else if (lNext > 0) wload(wfn, s + PRE - KS);      // (uniform branch, once per k-step of the slot's tail)
+      }
+      if (u + BD < 4 * KS && !(u < 2 * KS && u + BD >= 2 * KS) && !(PINN_ABL & 32)) bload(u + BD);
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb) {
         if (s == 0) {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          accM[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u & 1], zero) : mfma_bf16(wh[fb][0], bh[u & 1], zero);
+          accM[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u % (BD + 1)], zero) : mfma_bf16(wh[fb][0], bh[u % (BD + 1)], zero);
           if (TERMS == 3) {
-            accM[fb][j] = mfma_bf16(wl[fb][0], bh[u & 1], accM[fb][j]);
-            accM[fb][j] = mfma_bf16(wh[fb][0], bh[u & 1], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wl[fb][0], bh[u % (BD + 1)], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wh[fb][0], bh[u % (BD + 1)], accM[fb][j]);
           }
         } else {
           if (TERMS == 3) {
-            accM[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u & 1], accM[fb][j]);
-            accM[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u & 1], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u % (BD + 1)], accM[fb][j]);
+            accM[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u % (BD + 1)], accM[fb][j]);
           }
-          accM[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u & 1], accM[fb][j]);
+          accM[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u % (BD + 1)], accM[fb][j]);
         }
       }
     };
@@ -150,6 +192,7 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
     // into bf16 hi/lo and park them (or fold them into the output layer), spill the saved plane.
     auto eslice = [&](int q, int i) {
       const int fb = q >> 2, g = q & 3, ob = 32 * (fb * NW + w);
+      if (PINN_ABL & 4) return;
       if (i < 4) {
         const int e = i, r = 4 * g + e;
         float z, zx, zy, zd;
@@ -162,7 +205,8 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
           z = fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e])); zx = wx4[e]; zy = wy4[e]; zd = 0.f;
         } else {
           if (e == 0) b4 = *reinterpret_cast<const f32x4*>(bE + ob + 8 * g + 4 * h);
-          z = accE[fb][0][r] + b4[e]; zx = accE[fb][1][r]; zy = accE[fb][2][r]; zd = accE[fb][3][r];
+          z = acc_read(accE[fb][0][r]) + b4[e]; zx = acc_read(accE[fb][1][r]); zy = acc_read(accE[fb][2][r]);
+          zd = acc_read(accE[fb][3][r]);
         }
         const float t = fast_tanh(z);
         const float d1 = 1.f - t * t;
@@ -176,8 +220,10 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
           // slot while R2 is read
           const int obo = 32 * ((1 - fb) * NW + w);
           const int off = XI::chunk_off(col, (obo >> 3) + g) + 8 * h;
-          *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = st[g][p][0];
-          if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = st[g][p][1];
+          if (!(PINN_ABL & 16)) {
+            *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = st[g][p][0];
+            if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = st[g][p][1];
+          }
         }
         if (!last) {
           split4(av[p][0], av[p][1], av[p][2], av[p][3], st[g][p][0], st[g][p][1]);
@@ -190,16 +236,23 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) po[c][p] = fmaf(wo[e], av[p][e], po[c][p]);
           }
+          // keep the partial dot products HERE: left alone the optimiser sinks all 384 of them behind the step loop
+          // and spills the a-streams they need (46 serialised scratch reloads per tile)
+          asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));
         }
         const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + col);
-        __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+        if (!(PINN_ABL & 1)) __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
       }
     };
 
     if (doM) {
+      if (PINN_ABL & 2) {
 #pragma unroll
-      for (int s = 0; s < PRE; ++s) wload(s);
-      bload(0);
+        for (int s = 0; s < RING; ++s) wload(wf, s);
+      }
+#pragma unroll
+      for (int u = 0; u < BD; ++u) bload(u);
+      if (PINN_ABL & 32) bload(BD);
     }
     // 4 KS steps of 6 MFMAs, each with one epilogue slice in its shadow; nothing crosses a step boundary, so the
     // requests (weights PRE k-steps ahead, B fragments one step ahead) stay where they are written
@@ -207,9 +260,15 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
     static_assert(NSTEP == 64, "HP must be 256 (8 steps per register quad, 4 quads per sub-slot)");
 #pragma unroll
     for (int u = 0; u < NSTEP; ++u) {
+      if (u == 0) STAMP();
       if (u == NSTEP / 2) {
-        __syncthreads();                  // R1 has been read by every wave, R2 is complete
-        if (doM) bload(u);
+        STAMP();
+        if (!(PINN_ABL & 8)) __syncthreads();                  // R1 has been read by every wave, R2 is complete
+        STAMP();
+        if (doM) {
+#pragma unroll
+          for (int k = 0; k < BD; ++k) bload(u + k);
+        }
       }
       if (doM) jstep(u);
       eslice(u / 8, u % 8);
@@ -221,6 +280,11 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP();
+    if (!doM && lNext > 0) {      // an epilogue-only slot in front of a GEMM slot: its first weight fragments
+#pragma unroll
+      for (int s = 0; s < PRE; ++s) wload(wfn, s);
     }
     if (last) {
       // the lane pair (l, l + 32) holds the same column: add the halves (both publish the same value)
@@ -252,19 +316,19 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
   for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
     const int tA = 2 * pair, tB = 2 * pair + 1;      // tB == ntiles: a dummy tile (masked points, scratch S block)
     f32x16 accA[2][4], accB[2][4];
-    slot(F_{}, K0{}, F_{}, accB, 1, accA, 0, tA, partA);                        //            E_0(A)
+    slot(F_{}, K0{}, F_{}, accB, 1, 1, accA, 0, tA, partA);                     //            E_0(A)
     __syncthreads();
-    slot(T_{}, K0{}, T_{}, accA, 1, accB, 0, tB, partB);                        // M_1(A)   + E_0(B)
+    slot(T_{}, K0{}, T_{}, accA, 1, 1, accB, 0, tB, partB);                     // M_1(A)   + E_0(B)
     __syncthreads();
     for (int l = 1; l < L - 1; ++l) {
-      slot(T_{}, K1{}, T_{}, accB, l, accA, l, tA, partA);                      // M_l(B)   + E_l(A)
+      slot(T_{}, K1{}, T_{}, accB, l, l + 1, accA, l, tA, partA);               // M_l(B)   + E_l(A)
       __syncthreads();
-      slot(T_{}, K1{}, T_{}, accA, l + 1, accB, l, tB, partB);                  // M_l+1(A) + E_l(B)
+      slot(T_{}, K1{}, T_{}, accA, l + 1, l + 1, accB, l, tB, partB);           // M_l+1(A) + E_l(B)
       __syncthreads();
     }
-    slot(T_{}, K2{}, T_{}, accB, L - 1, accA, L - 1, tA, partA);                // M_L-1(B) + E_L-1(A), output layer
+    slot(T_{}, K2{}, T_{}, accB, L - 1, 0, accA, L - 1, tA, partA);             // M_L-1(B) + E_L-1(A), output layer
     __syncthreads();
-    slot(F_{}, K2{}, F_{}, accA, 1, accB, L - 1, tB, partB);                    //            E_L-1(B)
+    slot(F_{}, K2{}, F_{}, accA, 1, 0, accB, L - 1, tB, partB);                 //            E_L-1(B)
     __syncthreads();
     points(tA, partA, outvA);
     points(tB, partB, outvB);
