@@ -49,6 +49,7 @@ struct pinn_plan_s {
   int streams, ntiles, npad;
   int grid_f, grid_b, groups;
   int pipe_f, grid_fp;   // software-pipelined forward (fwd_bf16_pipe.hip) usable for this plan; its grid (pairs of tiles)
+  int pipe_b;            // software-pipelined reverse sweep (bwd_bf16_pipe.hip); grid_b is then its grid
   // workspace offsets in bytes
   size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
 };
@@ -84,6 +85,7 @@ static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s
 static int dispatch_bwd(const pinn_plan_s* plan, const BwdArgs& a, hipStream_t s) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (plan->pipe_b) return launch_bwd_pipe(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (n.prec_bwd)
     return n.HP > 256 ? launch_bwd_bf16_wide(n.HP, NS, terms_of(n.prec_bwd), a, plan->grid_b, s)
                       : launch_bwd_bf16(n.HP, NS, terms_of(n.prec_bwd), cols, a, plan->grid_b, s);
@@ -165,15 +167,23 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
   // residual mode, bf16 MFMA, hidden 256, >= 2 hidden layers: the one-wave-per-SIMD pipelined forward
   // (PINN_PIPE=0 opts out); forward-only calls (save = 0) keep the 8-wave kernel
-  p->pipe_f = net->prec_fwd != 0 && HP == 256 && !wide && streams == 4 && L >= 2 && env_int("PINN_PIPE", 1) != 0 &&
+  // (PINN_PIPE=0/1 switches both pipelined sweeps, PINN_PIPE_FWD / PINN_PIPE_BWD one of them).  Defaults from the
+  // round-2 measurements at 6x256 / 360k points: the pipelined forward is 7-8 % faster than the 8-wave kernel
+  // (2.65-2.69 vs 2.88 ms), the pipelined reverse sweep is at parity (3.73-3.88 vs 3.76 ms) and stays opt-in.
+  const int pipe_all = env_int("PINN_PIPE", -1);
+  const bool pipe_shape = HP == 256 && !wide && streams == 4 && L >= 2;
+  p->pipe_f = net->prec_fwd != 0 && pipe_shape && env_int("PINN_PIPE_FWD", pipe_all >= 0 ? pipe_all : 1) != 0 &&
               fwd_pipe_lds_bytes(HP, L) <= 163840;
+  p->pipe_b = net->prec_bwd != 0 && pipe_shape && env_int("PINN_PIPE_BWD", pipe_all >= 0 ? pipe_all : 0) != 0 &&
+              bwd_pipe_lds_bytes(HP, L) <= 163840;
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   if (env_int("PINN_VERBOSE", 0))
     fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, pipelined fwd %d (lds %zu)\n",
             (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f,
-            fwd_pipe_lds_bytes(HP, L));
+            fwd_pipe_lds_bytes(HP, L)), fprintf(stderr, "[pinn]       pipelined bwd %d (lds %zu)\n", p->pipe_b, bwd_pipe_lds_bytes(HP, L));
   p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
+  if (p->pipe_b) p->grid_b = p->grid_fp;
   if (L > 1) {
     int g = cus * bpc(lds_d) / (L - 1);
     if (g < 1) g = 1;

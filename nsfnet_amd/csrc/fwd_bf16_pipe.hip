@@ -180,7 +180,7 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) po[c][s] = 0.f;
     f32x4 av[4], sv[4];                   // a-streams / saved streams (t, z_x, z_y, z_D) of the register quad in flight
-    f32x4 b4, wx4, wy4;
+    f32x4 b4, wx4, wy4, b4n, wx4n, wy4n;      // (n: requested one quad ahead, so no step waits on its own LDS read)
     float px = 0.f, py = 0.f;
     if (first) {
       const int pt = tileE * PPL + col;
@@ -190,21 +190,26 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
     // per 6-MFMA step of the GEMM: slices 0-3 = tanh chain rule of element e, slices 4-7 = plane (stream) p: write
     // the parked quad (g, p) of the OTHER block into the image half the GEMM is not reading, split the new values
     // into bf16 hi/lo and park them (or fold them into the output layer), spill the saved plane.
+    // per-quad parameters from LDS: the bias (layer 0: w0x, w0y, b0) of features ob + 8g + 4h + 0..3
+    auto qparams = [&](int q) {
+      const int o = 32 * ((q >> 2) * NW + w) + 8 * (q & 3) + 4 * h;
+      if (first) {
+        wx4n = *reinterpret_cast<const f32x4*>(w0L + o); wy4n = *reinterpret_cast<const f32x4*>(w0L + HP + o);
+        b4n = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
+      } else {
+        b4n = *reinterpret_cast<const f32x4*>(bE + o);
+      }
+    };
     auto eslice = [&](int q, int i) {
       const int fb = q >> 2, g = q & 3, ob = 32 * (fb * NW + w);
       if (PINN_ABL & 4) return;
       if (i < 4) {
         const int e = i, r = 4 * g + e;
         float z, zx, zy, zd;
+        if (e == 0) { b4 = b4n; if (first) { wx4 = wx4n; wy4 = wy4n; } }
         if (first) {
-          if (e == 0) {
-            const int o = ob + 8 * g + 4 * h;
-            wx4 = *reinterpret_cast<const f32x4*>(w0L + o); wy4 = *reinterpret_cast<const f32x4*>(w0L + HP + o);
-            b4 = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
-          }
           z = fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e])); zx = wx4[e]; zy = wy4[e]; zd = 0.f;
         } else {
-          if (e == 0) b4 = *reinterpret_cast<const f32x4*>(bE + ob + 8 * g + 4 * h);
           z = acc_read(accE[fb][0][r]) + b4[e]; zx = acc_read(accE[fb][1][r]); zy = acc_read(accE[fb][2][r]);
           zd = acc_read(accE[fb][3][r]);
         }
@@ -215,6 +220,7 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
         sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
       } else {
         const int p = i - 4;
+        if (p == 0 && q + 1 < 8) qparams(q + 1);
         if (fb == 0 ? dump1 : !last) {
           // parked quad (g, p) of the other block: R2 data of the previous slot while R1 is read, R1 data of this
           // slot while R2 is read
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
       }
     };
 
+    qparams(0);
     if (doM) {
       if (PINN_ABL & 2) {
 #pragma unroll
@@ -275,8 +282,13 @@ __global__ __launch_bounds__(HP, 1) void fwd_pipe_kernel(FwdArgs a) {
       if (doM) {
 #pragma unroll
         for (int i = 0; i < (TERMS == 3 ? 6 : 2); ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 8, 0);   // epilogue VALU in its shadow
+#ifndef PINN_VPM
+#define PINN_VPM 3
+#endif
+          if (PINN_VPM > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? PINN_VPM : 3 * PINN_VPM, 0);   // epilogue VALU in its shadow
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);

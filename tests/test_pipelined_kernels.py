@@ -1,4 +1,4 @@
-"""The software-pipelined (one wave per SIMD, two tiles in flight) bf16 kernels against the 8-wave kernels they
+"""The software-pipelined (one wave per SIMD, two tiles in flight) bf16 forward and reverse sweeps against the 8-wave kernels they
 replace for hidden = 256 and against the fp64 oracle: same fields, loss sums, saved activations (seen through the
 gradient the reverse sweep computes from them) for even / odd / single tile counts, ragged point counts, 2..7 hidden
 layers, both bf16 modes, plain and ev flavour.  The two schedules sum in a different order (bias added after the
@@ -18,6 +18,8 @@ H = 256
 def _run(monkeypatch, pipe, L, N, prec, ev=False):
     from nsfnet_amd import engine as eng
     monkeypatch.setenv("PINN_PIPE", "1" if pipe else "0")
+    for k in ("PINN_PIPE_FWD", "PINN_PIPE_BWD"):
+        monkeypatch.delenv(k, raising=False)
     dev = torch.device("cuda:0")
     flat = ar.flat_params(ar.seeded_net(3, L, H, seed=40 + L)).numpy().copy()
     rng = np.random.RandomState(N)
@@ -46,20 +48,25 @@ def _run(monkeypatch, pipe, L, N, prec, ev=False):
 def test_pipelined_forward_matches_8wave_kernels(monkeypatch, L, N, prec):
     a = _run(monkeypatch, True, L, N, prec)
     b = _run(monkeypatch, False, L, N, prec)
-    # bf16x3: the hi/lo splits of slightly different intermediates round differently (~2^-17 per product); plain bf16:
-    # operands rounded to 8 bits, order effects are plainly visible
-    tol = 3e-5 if prec == "bf16x3" else 2e-2
+    # bf16x3: the hi/lo splits of slightly different intermediates round differently (~2^-17 per product, more on the
+    # small derivative planes); plain bf16: operands rounded to 8 bits, order effects are plainly visible
+    tol = 2e-4 if prec == "bf16x3" else 5e-2
     for k in range(a["fields"].shape[0]):
         scale = max(np.abs(b["fields"][k]).max(), 1e-30)
         assert np.abs(a["fields"][k] - b["fields"][k]).max() <= tol * scale, k
-    np.testing.assert_allclose(a["sums"][:4], b["sums"][:4], rtol=10 * tol, atol=1e-30)
-    assert np.linalg.norm(a["grads"] - b["grads"]) <= 10 * tol * np.linalg.norm(b["grads"])
+    np.testing.assert_allclose(a["sums"][:4], b["sums"][:4], rtol=tol, atol=1e-30)
+    assert np.linalg.norm(a["grads"] - b["grads"]) <= (1e-4 if prec == "bf16x3" else 5e-2) * np.linalg.norm(b["grads"])
     if prec == "bf16x3":      # and against the fp64 oracle at the bf16x3 bars
         P = fr.unflatten(a["flat"].astype(np.float64), 2, 3, L, H)
         r = fr.pde_loss_and_grad(P, a["x"].astype(np.float64), a["y"].astype(np.float64), 1500.0, alpha_e=1.0)
         for k, name in ((6, "eq1"), (7, "eq2"), (8, "eq3")):
             assert np.abs(a["fields"][k] - r["eqs"][k - 6]).max() < 5e-4 * np.abs(r["eqs"][k - 6]).max(), name
         np.testing.assert_allclose(a["sums"][:3], r["sums"], rtol=2e-4)
+        xb, yb, ub, vb = (q.reshape(-1)[::16].astype(np.float64) for q in ar.cavity_boundary())
+        bq = fr.bc_loss_and_grad(P, xb.astype(np.float32).astype(np.float64), yb.astype(np.float32).astype(np.float64),
+                                 ub.astype(np.float32), vb.astype(np.float32), alpha_b=10.0)
+        g_ref = r["grad"] + bq["grad"]
+        assert np.linalg.norm(a["grads"] - g_ref) <= 1e-4 * np.linalg.norm(g_ref)      # pipelined reverse sweep vs fp64
 
 
 def test_pipelined_forward_ev_flavour(monkeypatch):
@@ -67,7 +74,7 @@ def test_pipelined_forward_ev_flavour(monkeypatch):
     b = _run(monkeypatch, False, 5, 450, "bf16x3", ev=True)
     for k in range(a["fields"].shape[0]):
         scale = max(np.abs(b["fields"][k]).max(), 1e-30)
-        assert np.abs(a["fields"][k] - b["fields"][k]).max() <= 3e-5 * scale, k
+        assert np.abs(a["fields"][k] - b["fields"][k]).max() <= 2e-4 * scale, k
     np.testing.assert_array_equal(a["vis"], b["vis"])
     np.testing.assert_allclose(a["sums"][:4], b["sums"][:4], rtol=1e-4)
     assert np.linalg.norm(a["grads"] - b["grads"]) <= 1e-4 * np.linalg.norm(b["grads"])
