@@ -252,16 +252,6 @@ def build_engine(eng, dev, args, precision, pg, world, rank):
     return E
 
 
-def kernel_names(args, prec):
-    H = args.hidden
-    wide = H > 256 or (H > 224 and prec == "fp32")      # 64-column-tile kernels (csrc/capi.hip pick_wide)
-    if prec == "fp32":
-        return ("fwd_wide_kernel", "bwd_wide_kernel", "dw_wide_kernel") if wide else ("fwd_kernel", "bwd_kernel", "dw_kernel")
-    if H > 256:                                          # wide nets: 64 features per wave, blocked dW
-        return ("fwd_bf16_wide_kernel", "bwd_bf16_wide_kernel", "dw_bf16_wide_kernel")
-    return ("fwd_bf16_kernel", "bwd_bf16_kernel", "dw_bf16_kernel")
-
-
 def kernel_report(E_, args, prec, ms_step, n_local, n_global):
     L, H, Re = args.layers, args.hidden, args.re
     f = E_.plan_f
@@ -281,7 +271,7 @@ def kernel_report(E_, args, prec, ms_step, n_local, n_global):
     log("[%s] kernel ms: fwd %.3f bwd %.3f dw %.3f" % (prec, t_fwd, t_bwd, t_dw))
     pw = weight_count(L, H)
     flops_each = 8.0 * pw * n_launch       # fwd, dX sweep and dW GEMM each carry 2*4*P_w FLOP per point
-    kernels = dict(zip(kernel_names(args, prec), (t_fwd, t_bwd, t_dw)))
+    kernels = dict(zip(f.kernel_names(), (t_fwd, t_bwd, t_dw)))
     dom = max(kernels, key=kernels.get)
     achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
     peak = MFMA_PEAK_TFLOPS[prec]

@@ -35,7 +35,7 @@ enum {
 #define PINN_NLOSS 8
 
 const char* pinn_last_error(void);
-/* 2 = this header (1 + pinn_adam_step_dev; bf16 modes for every width up to 512). */
+/* 3 = this header (2 + pinn_plan_kernel; 2 = 1 + pinn_adam_step_dev, bf16 modes for every width up to 512). */
 int pinn_abi_version(void);
 
 /* ---- network description --------------------------------------------------
@@ -64,6 +64,10 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
 int pinn_plan_destroy(pinn_plan_t plan);
 int64_t pinn_plan_padded_points(pinn_plan_t plan);
 int64_t pinn_plan_workspace_bytes(pinn_plan_t plan, int with_backward);
+/* Name of the kernel family the plan launches for `which` = 0 forward (with saved activations), 1 reverse sweep,
+ * 2 weight-gradient GEMM - what appears in a rocprofv3 kernel trace (e.g. "fwd_pipe_kernel", "bwd_bf16_kernel").
+ * For profiling harnesses (bench.py keys its roofline / PMC lookup on it); static string, never NULL for a valid plan. */
+const char* pinn_plan_kernel(pinn_plan_t plan, int which);
 
 /* ---- residual forward -------------------------------------------------------
  * Replaces neural_net_equations + the PDE half of fwd_computing_loss_2d

@@ -23,6 +23,7 @@ SIGNATURES = {
     "pinn_plan_destroy": (c_int, [c_void_p]),
     "pinn_plan_padded_points": (c_int64, [c_void_p]),
     "pinn_plan_workspace_bytes": (c_int64, [c_void_p, c_int]),
+    "pinn_plan_kernel": (ctypes.c_char_p, [c_void_p, c_int]),
     "pinn_residual_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                                       c_int, c_void_p, c_void_p]),

@@ -102,7 +102,7 @@ static int dispatch_dw(const pinn_plan_s* plan, const DwArgs& d, hipStream_t s) 
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err; }
-int pinn_abi_version(void) { return 2; }   // 2: + pinn_adam_step_dev, hidden <= 512 in every precision mode
+int pinn_abi_version(void) { return 3; }   // 3: + pinn_plan_kernel; 2: + pinn_adam_step_dev, hidden <= 512 in every precision mode
 
 int pinn_net_create(int n_out, int n_hidden_layers, int hidden, pinn_net_t* out) {
   if (!out) return fail(-22, "pinn_net_create: null out%s");
@@ -223,6 +223,16 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
 }
 int pinn_plan_destroy(pinn_plan_t plan) { delete plan; return 0; }
 int64_t pinn_plan_padded_points(pinn_plan_t plan) { return plan ? plan->npad : -1; }
+const char* pinn_plan_kernel(pinn_plan_t plan, int which) {
+  if (!plan || which < 0 || which > 2) return nullptr;
+  const pinn_net_s& n = plan->net;
+  const bool wbf = n.HP > 256;
+  if (which == 0) return plan->pipe_f ? "fwd_pipe_kernel" : n.prec_fwd ? (wbf ? "fwd_bf16_wide_kernel" : "fwd_bf16_kernel")
+                                      : n.wide ? "fwd_wide_kernel" : "fwd_kernel";
+  if (which == 1) return plan->pipe_b ? "bwd_pipe_kernel" : n.prec_bwd ? (wbf ? "bwd_bf16_wide_kernel" : "bwd_bf16_kernel")
+                                      : n.wide ? "bwd_wide_kernel" : "bwd_kernel";
+  return n.prec_dw ? (wbf ? "dw_bf16_wide_kernel" : "dw_bf16_kernel") : n.wide ? "dw_wide_kernel" : "dw_kernel";
+}
 int64_t pinn_plan_workspace_bytes(pinn_plan_t plan, int with_backward) {
   if (!plan) return -1;
   return (int64_t)(with_backward ? plan->bytes_all : plan->bytes_fwd);

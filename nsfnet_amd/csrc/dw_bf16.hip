@@ -94,7 +94,10 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
     } else {
       av[0] = sr[0]; av[1] = sr[1]; av[2] = sr[2]; av[3] = sr[3];
     }
-    unsigned char* base = ldsb + (size_t)buf * 4 * DI::ARR + p * DI::RSB + og * 8;
+    // 8-byte column XOR-swizzled by the row: with the row stride == 16 dwords (mod 32) the 16 lanes of a
+    // ds_write_b64 group (8 rows x 2 columns) would otherwise fall on 8 banks (4-way conflict: SQ_LDS_BANK_CONFLICT
+    // 3.5e8 cycles per launch at 6x256 / 360k points, more than the LDS-active cycles of the reads)
+    unsigned char* base = ldsb + (size_t)buf * 4 * DI::ARR + p * DI::RSB + (og ^ (p & 6)) * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       u32x2 hi, lo;
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
   };
   // transposed-read lane geometry: 16-lane group gq = lane>>4 -> feature half fb, k half (== h)
   const int li = lane & 15, fb = (lane >> 4) & 1, q = li >> 2, pp = li & 3;
-  const int lane_off = (8 * h + q) * DI::RSB + (16 * fb + 4 * pp) * 2;
+  // (the two 4-row blocks of a fragment sit in rows q and q + 4 of their 8-row group: un-swizzle each with its row)
+  const int lane_off = (8 * h + q) * DI::RSB + ((4 * fb + pp) ^ (q & 2)) * 8;
+  const int lane_off4 = (8 * h + q + 4) * DI::RSB + ((4 * fb + pp) ^ ((q & 2) | 4)) * 8 - lane_off;
   auto mfma_chunk = [&](int buf) {
     const lds_u8* B0 = (const lds_u8*)ldsb + buf * 4 * DI::ARR + lane_off;
 #pragma unroll
@@ -118,20 +123,20 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
 #pragma unroll
       for (int m = 0; m < TM; ++m) {
         const lds_u8* pz = B0 + ks * 16 * DI::RSB + 64 * (wr * TM + m);
-        u32x2 x0 = tr_read(pz), x1 = tr_read(pz + 4 * DI::RSB);
+        u32x2 x0 = tr_read(pz), x1 = tr_read(pz + lane_off4);
         zh[m][0] = x0[0]; zh[m][1] = x0[1]; zh[m][2] = x1[0]; zh[m][3] = x1[1];
         if (TERMS == 3) {
-          u32x2 y0 = tr_read(pz + DI::ARR), y1 = tr_read(pz + DI::ARR + 4 * DI::RSB);
+          u32x2 y0 = tr_read(pz + DI::ARR), y1 = tr_read(pz + DI::ARR + lane_off4);
           zl[m][0] = y0[0]; zl[m][1] = y0[1]; zl[m][2] = y1[0]; zl[m][3] = y1[1];
         }
       }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         const lds_u8* pa = B0 + 2 * DI::ARR + ks * 16 * DI::RSB + 64 * (wc * TN + n);
-        u32x2 x0 = tr_read(pa), x1 = tr_read(pa + 4 * DI::RSB);
+        u32x2 x0 = tr_read(pa), x1 = tr_read(pa + lane_off4);
         ah[n][0] = x0[0]; ah[n][1] = x0[1]; ah[n][2] = x1[0]; ah[n][3] = x1[1];
         if (TERMS == 3) {
-          u32x2 y0 = tr_read(pa + DI::ARR), y1 = tr_read(pa + DI::ARR + 4 * DI::RSB);
+          u32x2 y0 = tr_read(pa + DI::ARR), y1 = tr_read(pa + DI::ARR + lane_off4);
           al[n][0] = y0[0]; al[n][1] = y0[1]; al[n][2] = y1[0]; al[n][3] = y1[1];
         }
       }

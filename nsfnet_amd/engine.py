@@ -159,6 +159,10 @@ class PointPlan:
         self.ws = ws if ws is not None else torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
         self.sums = torch.zeros(NLOSS, dtype=torch.float32, device=dev)
 
+    def kernel_names(self):
+        """(forward, reverse sweep, weight-gradient) kernel family names this plan launches (for profiling)."""
+        return tuple((self.lib.pinn_plan_kernel(self.handle, k) or b"").decode() for k in (0, 1, 2))
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_host_only_entry_points(lib):
-    assert lib.pinn_abi_version() == 2
+    assert lib.pinn_abi_version() == 3
     h = ctypes.c_void_p()
     assert lib.pinn_net_create(3, 6, 256, ctypes.byref(h)) == 0
     assert lib.pinn_net_num_params(h) == fr.param_count(2, 3, 6, 256) == 330499
@@ -51,6 +51,12 @@ def test_host_only_entry_points(lib):
     q2 = ctypes.c_void_p()
     assert lib.pinn_plan_create(h, 2052, 1, ctypes.byref(q2)) == 0
     assert lib.pinn_plan_padded_points(q2) == 2176         # 17 tiles of 128 points
+    p2 = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p2)) == 0
+    assert [lib.pinn_plan_kernel(p2, k) for k in (0, 1, 2)] == [b"fwd_pipe_kernel", b"bwd_bf16_kernel", b"dw_bf16_kernel"]
+    assert [lib.pinn_plan_kernel(p, k) for k in (0, 1, 2)] == [b"fwd_wide_kernel", b"bwd_wide_kernel", b"dw_wide_kernel"]
+    assert lib.pinn_plan_kernel(q2, 0) == b"fwd_bf16_kernel" and lib.pinn_plan_kernel(p2, 3) is None
+    lib.pinn_plan_destroy(p2)
     lib.pinn_plan_destroy(q2)
     for handle in (p, q):
         assert lib.pinn_plan_destroy(handle) == 0
