@@ -138,7 +138,11 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) oc[c][s] = oadjE[c * COLS + s * PPL + col];
     }
-    f32x4 sc[4], sn[4];            // saved (t, z_x, z_y, z_D) of the quad in flight / of the next quad (requested a quad ahead)
+#ifndef PINN_SD
+#define PINN_SD 1
+#endif
+    constexpr int SD = PINN_SD;    // S quads requested ahead of their chain rule (HBM latency: several quads' worth)
+    f32x4 sq[SD + 1][4];           // saved (t, z_x, z_y, z_D): ring over quads
     f32x4 zq[4];                   // z-bar of the quad: [stream][element]
     f32x4 wov[3], dwv[2];          // per-element column terms of dW_out (first) / dW_0 (last)
     f32x4 wo4[3];
@@ -165,9 +169,7 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
       if (i < 4) {
         const int e = i, r = 4 * g + e;
         if (e == 0) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) sc[p] = sn[p];
-          if (q + 1 < 8) sload(q + 1, sn);
+          if (q + SD < 8) sload(q + SD, sq[(q + SD) % (SD + 1)]);
           if (first) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) wo4[c] = *reinterpret_cast<const f32x4*>(woutL + c * HP + ob + 8 * g + 4 * h);
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
           ga = acc_read_b(accE[fb][0][r]); gx = acc_read_b(accE[fb][1][r]); gy = acc_read_b(accE[fb][2][r]);
           gd = acc_read_b(accE[fb][3][r]);
         }
+        const f32x4 (&sc)[4] = sq[q % (SD + 1)];
         const float t = sc[0][e], zx = sc[1][e], zy = sc[2][e], zd = sc[3][e];
         const float d1 = 1.f - t * t;
         const float d2 = -2.f * t * d1;
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
 #pragma unroll
       for (int u = 0; u < BD; ++u) bload(u);
     }
-    sload(0, sn);
+#pragma unroll
+    for (int q = 0; q < SD; ++q) sload(q, sq[q]);
     constexpr int NSTEP = 4 * KS;
     static_assert(NSTEP == 64, "HP must be 256");
 #pragma unroll
