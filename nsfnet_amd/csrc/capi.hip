@@ -76,7 +76,8 @@ static int env_int(const char* name, int dflt) {
 static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s, bool pipe = false) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
-  if (pipe) return launch_fwd_pipe(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s);
+  if (pipe) return plan->pipe_f == 2 ? launch_fwd_split(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s)
+                                     : launch_fwd_pipe(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s);
   if (n.prec_fwd)
     return n.HP > 256 ? launch_fwd_bf16_wide(n.HP, NS, terms_of(n.prec_fwd), a, plan->grid_f, s)
                       : launch_fwd_bf16(n.HP, NS, terms_of(n.prec_fwd), cols, a, plan->grid_f, s);
@@ -174,6 +175,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   const bool pipe_shape = HP == 256 && !wide && streams == 4 && L >= 2;
   p->pipe_f = net->prec_fwd != 0 && pipe_shape && env_int("PINN_PIPE_FWD", pipe_all >= 0 ? pipe_all : 1) != 0 &&
               fwd_pipe_lds_bytes(HP, L) <= 163840;
+  if (p->pipe_f && env_int("PINN_SPLIT_FWD", 0) != 0 && fwd_split_lds_bytes(HP, L) <= 163840) p->pipe_f = 2;
   p->pipe_b = net->prec_bwd != 0 && pipe_shape && env_int("PINN_PIPE_BWD", pipe_all >= 0 ? pipe_all : 0) != 0 &&
               bwd_pipe_lds_bytes(HP, L) <= 163840;
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
@@ -227,7 +229,7 @@ const char* pinn_plan_kernel(pinn_plan_t plan, int which) {
   if (!plan || which < 0 || which > 2) return nullptr;
   const pinn_net_s& n = plan->net;
   const bool wbf = n.HP > 256;
-  if (which == 0) return plan->pipe_f ? "fwd_pipe_kernel" : n.prec_fwd ? (wbf ? "fwd_bf16_wide_kernel" : "fwd_bf16_kernel")
+  if (which == 0) return plan->pipe_f == 2 ? "fwd_split_kernel" : plan->pipe_f ? "fwd_pipe_kernel" : n.prec_fwd ? (wbf ? "fwd_bf16_wide_kernel" : "fwd_bf16_kernel")
                                       : n.wide ? "fwd_wide_kernel" : "fwd_kernel";
   if (which == 1) return plan->pipe_b ? "bwd_pipe_kernel" : n.prec_bwd ? (wbf ? "bwd_bf16_wide_kernel" : "bwd_bf16_kernel")
                                       : n.wide ? "bwd_wide_kernel" : "bwd_kernel";

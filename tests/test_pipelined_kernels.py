@@ -16,8 +16,11 @@ H = 256
 
 
 def _run(monkeypatch, pipe, L, N, prec, ev=False):
+    """pipe: False = 8-wave kernels, True = one-wave-per-SIMD pipelined sweeps, "split" = role-split forward (two
+    wave groups in opposite phases) + pipelined reverse sweep."""
     from nsfnet_amd import engine as eng
     monkeypatch.setenv("PINN_PIPE", "1" if pipe else "0")
+    monkeypatch.setenv("PINN_SPLIT_FWD", "1" if pipe == "split" else "0")
     for k in ("PINN_PIPE_FWD", "PINN_PIPE_BWD"):
         monkeypatch.delenv(k, raising=False)
     dev = torch.device("cuda:0")
@@ -45,8 +48,9 @@ def _run(monkeypatch, pipe, L, N, prec, ev=False):
 
 @pytest.mark.parametrize("L,N", [(6, 320), (6, 330), (6, 20), (2, 97), (3, 640), (7, 65), (4, 2049)])
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
-def test_pipelined_forward_matches_8wave_kernels(monkeypatch, L, N, prec):
-    a = _run(monkeypatch, True, L, N, prec)
+@pytest.mark.parametrize("sched", [True, "split"])
+def test_pipelined_forward_matches_8wave_kernels(monkeypatch, L, N, prec, sched):
+    a = _run(monkeypatch, sched, L, N, prec)
     b = _run(monkeypatch, False, L, N, prec)
     # bf16x3: the hi/lo splits of slightly different intermediates round differently (~2^-17 per product, more on the
     # small derivative planes); plain bf16: operands rounded to 8 bits, order effects are plainly visible
@@ -69,8 +73,9 @@ def test_pipelined_forward_matches_8wave_kernels(monkeypatch, L, N, prec):
         assert np.linalg.norm(a["grads"] - g_ref) <= 1e-4 * np.linalg.norm(g_ref)      # pipelined reverse sweep vs fp64
 
 
-def test_pipelined_forward_ev_flavour(monkeypatch):
-    a = _run(monkeypatch, True, 5, 450, "bf16x3", ev=True)
+@pytest.mark.parametrize("sched", [True, "split"])
+def test_pipelined_forward_ev_flavour(monkeypatch, sched):
+    a = _run(monkeypatch, sched, 5, 450, "bf16x3", ev=True)
     b = _run(monkeypatch, False, 5, 450, "bf16x3", ev=True)
     for k in range(a["fields"].shape[0]):
         scale = max(np.abs(b["fields"][k]).max(), 1e-30)
