@@ -48,8 +48,8 @@ struct pinn_plan_s {
   long n;
   int streams, ntiles, npad;
   int grid_f, grid_b, groups;
-  int pipe_f, grid_fp;   // software-pipelined forward (fwd_bf16_pipe.hip) usable for this plan; its grid (pairs of tiles)
-  int pipe_b;            // software-pipelined reverse sweep (bwd_bf16_pipe.hip); grid_b is then its grid
+  int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
+  int pipe_b;            // schedule of the reverse sweep; for 1 / 2 grid_b is the pair grid
   // workspace offsets in bytes
   size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
 };
@@ -86,6 +86,7 @@ static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s
 static int dispatch_bwd(const pinn_plan_s* plan, const BwdArgs& a, hipStream_t s) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (plan->pipe_b == 2) return launch_bwd_split(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (plan->pipe_b) return launch_bwd_pipe(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (n.prec_bwd)
     return n.HP > 256 ? launch_bwd_bf16_wide(n.HP, NS, terms_of(n.prec_bwd), a, plan->grid_b, s)
@@ -166,23 +167,27 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (lds_b > 163840 || lds_f > 163840) { delete p; return fail(-22, "pinn_plan_create: this depth x width needs more than 160 KiB of LDS%s"); }
   p->grid_f = cus * bpc(lds_f);
   if (p->grid_f > p->ntiles) p->grid_f = p->ntiles;
-  // residual mode, bf16 MFMA, hidden 256, >= 2 hidden layers: the one-wave-per-SIMD pipelined forward
-  // (PINN_PIPE=0 opts out); forward-only calls (save = 0) keep the 8-wave kernel
-  // (PINN_PIPE=0/1 switches both pipelined sweeps, PINN_PIPE_FWD / PINN_PIPE_BWD one of them).  Defaults from the
-  // round-2 measurements at 6x256 / 360k points: the pipelined forward is 7-8 % faster than the 8-wave kernel
-  // (2.65-2.69 vs 2.88 ms), the pipelined reverse sweep is at parity (3.73-3.88 vs 3.76 ms) and stays opt-in.
-  const int pipe_all = env_int("PINN_PIPE", -1);
+  // (forward-only calls, save = 0, always take the 8-wave kernel)
+  // Schedule of the hidden-256 bf16 sweeps in residual mode: 0 = 8-wave kernels (fwd_bf16 / bwd_bf16), 1 = one wave
+  // per SIMD, two tiles per wave (fwd_bf16_pipe / bwd_bf16_pipe), 2 = two wave groups in opposite phases
+  // (fwd_bf16_split / bwd_bf16_split).  $PINN_FWD_SCHED / $PINN_BWD_SCHED choose per sweep, $PINN_SCHED both.
+  // Default 2.  Round-2 measurements at 6x256 / 360k points (ms): forward 2.88 / 2.69 / 2.65, reverse sweep
+  // 3.78 / 3.73-3.88 / 3.72 - the three schedules end within 8 % of each other (DESIGN.md section 4 says why).
   const bool pipe_shape = HP == 256 && !wide && streams == 4 && L >= 2;
-  p->pipe_f = net->prec_fwd != 0 && pipe_shape && env_int("PINN_PIPE_FWD", pipe_all >= 0 ? pipe_all : 1) != 0 &&
-              fwd_pipe_lds_bytes(HP, L) <= 163840;
-  if (p->pipe_f && env_int("PINN_SPLIT_FWD", 0) != 0 && fwd_split_lds_bytes(HP, L) <= 163840) p->pipe_f = 2;
-  p->pipe_b = net->prec_bwd != 0 && pipe_shape && env_int("PINN_PIPE_BWD", pipe_all >= 0 ? pipe_all : 0) != 0 &&
-              bwd_pipe_lds_bytes(HP, L) <= 163840;
+  const int sched_all = env_int("PINN_SCHED", 2);
+  int sf = env_int("PINN_FWD_SCHED", sched_all), sb = env_int("PINN_BWD_SCHED", sched_all);
+  if (!pipe_shape || !net->prec_fwd) sf = 0;
+  if (!pipe_shape || !net->prec_bwd) sb = 0;
+  if (sf == 2 && fwd_split_lds_bytes(HP, L) > 163840) sf = 1;
+  if (sf == 1 && fwd_pipe_lds_bytes(HP, L) > 163840) sf = 0;
+  if (sb == 2 && bwd_split_lds_bytes(HP, L) > 163840) sb = 1;
+  if (sb == 1 && bwd_pipe_lds_bytes(HP, L) > 163840) sb = 0;
+  p->pipe_f = sf < 0 || sf > 2 ? 0 : sf;
+  p->pipe_b = sb < 0 || sb > 2 ? 0 : sb;
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   if (env_int("PINN_VERBOSE", 0))
-    fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, pipelined fwd %d (lds %zu)\n",
-            (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f,
-            fwd_pipe_lds_bytes(HP, L)), fprintf(stderr, "[pinn]       pipelined bwd %d (lds %zu)\n", p->pipe_b, bwd_pipe_lds_bytes(HP, L));
+    fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, schedule fwd %d bwd %d\n",
+            (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f, p->pipe_b);
   p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
   if (p->pipe_b) p->grid_b = p->grid_fp;
@@ -231,7 +236,7 @@ const char* pinn_plan_kernel(pinn_plan_t plan, int which) {
   const bool wbf = n.HP > 256;
   if (which == 0) return plan->pipe_f == 2 ? "fwd_split_kernel" : plan->pipe_f ? "fwd_pipe_kernel" : n.prec_fwd ? (wbf ? "fwd_bf16_wide_kernel" : "fwd_bf16_kernel")
                                       : n.wide ? "fwd_wide_kernel" : "fwd_kernel";
-  if (which == 1) return plan->pipe_b ? "bwd_pipe_kernel" : n.prec_bwd ? (wbf ? "bwd_bf16_wide_kernel" : "bwd_bf16_kernel")
+  if (which == 1) return plan->pipe_b == 2 ? "bwd_split_kernel" : plan->pipe_b ? "bwd_pipe_kernel" : n.prec_bwd ? (wbf ? "bwd_bf16_wide_kernel" : "bwd_bf16_kernel")
                                       : n.wide ? "bwd_wide_kernel" : "bwd_kernel";
   return n.prec_dw ? (wbf ? "dw_bf16_wide_kernel" : "dw_bf16_kernel") : n.wide ? "dw_wide_kernel" : "dw_kernel";
 }

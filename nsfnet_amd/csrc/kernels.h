@@ -116,6 +116,8 @@ size_t fwd_pipe_lds_bytes(int HP, int L);
 // two wave groups in opposite phases (fwd_bf16_split.hip): HP = 256, residual mode
 int launch_fwd_split(int HP, int terms, const FwdArgs& a, int grid, hipStream_t s);
 size_t fwd_split_lds_bytes(int HP, int L);
+int launch_bwd_split(int HP, int terms, const BwdArgs& a, int grid, hipStream_t s);
+size_t bwd_split_lds_bytes(int HP, int L);
 int launch_bwd_pipe(int HP, int terms, const BwdArgs& a, int grid, hipStream_t s);
 size_t bwd_pipe_lds_bytes(int HP, int L);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);

@@ -1,4 +1,4 @@
-"""A/B of the pipelined vs 8-wave bf16x3 kernels at the headline shape, interleaved rounds in ONE process
+"""A/B/C of the 8-wave (0), pipelined (1) and role-split (2) bf16x3 sweeps at the headline shape, interleaved rounds in ONE process
 (cdna_hip_programming.md rule 24): per-kernel HIP-event times, min and median over rounds.
     python scripts/ab_pipe.py [--grid 600] [--rounds 5] [--prec bf16x3]"""
 import argparse, os, sys, json
@@ -20,8 +20,8 @@ def main():
     x, y = bench.grid_block(a.grid, a.grid, 0, 1)
     xb, yb, ub, vb = bench.cavity_boundary()
     E = {}
-    for pipe in ("0", "1"):
-        os.environ["PINN_PIPE"] = pipe
+    for pipe in ("0", "1", "2"):
+        os.environ["PINN_SCHED"] = pipe
         e = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, precision=a.prec)
         e.net.set_flat(bench.seeded_flat(L, H))
         e.set_collocation(x, y); e.set_boundary(xb, yb, ub, vb)
@@ -40,7 +40,7 @@ def main():
             res[k]["dw"].append(bench.time_kernel(lambda: f.backward(Re, (c, c, c, 0.0), phases=2), 5))
             res[k]["step"].append(bench.time_kernel(lambda: e.step(1e-3), 10))
     for k in E:
-        print("PINN_PIPE=%s  " % k + "  ".join("%s min %.3f med %.3f" % (n_, min(v), float(np.median(v))) for n_, v in res[k].items()),
+        print("PINN_SCHED=%s  " % k + "  ".join("%s min %.3f med %.3f" % (n_, min(v), float(np.median(v))) for n_, v in res[k].items()),
               " loss %.6f" % float(E[k].loss_terms()["loss"]), flush=True)
 
 

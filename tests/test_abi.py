@@ -53,7 +53,7 @@ def test_host_only_entry_points(lib):
     assert lib.pinn_plan_padded_points(q2) == 2176         # 17 tiles of 128 points
     p2 = ctypes.c_void_p()
     assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p2)) == 0
-    assert [lib.pinn_plan_kernel(p2, k) for k in (0, 1, 2)] == [b"fwd_pipe_kernel", b"bwd_bf16_kernel", b"dw_bf16_kernel"]
+    assert [lib.pinn_plan_kernel(p2, k) for k in (0, 1, 2)] == [b"fwd_split_kernel", b"bwd_split_kernel", b"dw_bf16_kernel"]
     assert [lib.pinn_plan_kernel(p, k) for k in (0, 1, 2)] == [b"fwd_wide_kernel", b"bwd_wide_kernel", b"dw_wide_kernel"]
     assert lib.pinn_plan_kernel(q2, 0) == b"fwd_bf16_kernel" and lib.pinn_plan_kernel(p2, 3) is None
     lib.pinn_plan_destroy(p2)

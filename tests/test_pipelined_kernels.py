@@ -17,11 +17,10 @@ H = 256
 
 def _run(monkeypatch, pipe, L, N, prec, ev=False):
     """pipe: False = 8-wave kernels, True = one-wave-per-SIMD pipelined sweeps, "split" = role-split forward (two
-    wave groups in opposite phases) + pipelined reverse sweep."""
+    wave groups in opposite phases) + role-split reverse sweep."""
     from nsfnet_amd import engine as eng
-    monkeypatch.setenv("PINN_PIPE", "1" if pipe else "0")
-    monkeypatch.setenv("PINN_SPLIT_FWD", "1" if pipe == "split" else "0")
-    for k in ("PINN_PIPE_FWD", "PINN_PIPE_BWD"):
+    monkeypatch.setenv("PINN_SCHED", {False: "0", True: "1", "split": "2"}[pipe])
+    for k in ("PINN_FWD_SCHED", "PINN_BWD_SCHED"):
         monkeypatch.delenv(k, raising=False)
     dev = torch.device("cuda:0")
     flat = ar.flat_params(ar.seeded_net(3, L, H, seed=40 + L)).numpy().copy()
