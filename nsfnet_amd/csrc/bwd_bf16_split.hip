@@ -9,7 +9,7 @@
 //     group 1:              E_{L-1}(B)  G_{L-1}(B)  ...          G_1(B)   E_0(B) | ...
 //
 // E_l = tanh adjoint of layer l: reads the saved (t, z_x, z_y, z_D) quads (requested SQ quads ahead: they stream from
-// HBM), turns the a-stream adjoints (accumulators of G_{l+1}; for l = L-1 the rank-3 update W_out^T o-bar) into z-bar,
+// HBM; layer 0's are recomputed from the point instead - the role-split forward does not spill them), turns the a-stream adjoints (accumulators of G_{l+1}; for l = L-1 the rank-3 update W_out^T o-bar) into z-bar,
 // column-sums the skinny gradients into the LDS accumulator, splits z-bar into bf16 hi/lo, spills it.
 // G_l = W_l^T z-bar_l (MFMA only).  One shared z-bar image, four K regions, 32 parked registers: fwd_bf16_split.hip.
 #include "kernels.h"
@@ -29,7 +29,7 @@ struct SplitBwdLds {
   static constexpr size_t X_BYTES = XI::BYTES;                          // THE z-bar image (shared by the two groups)
   static constexpr size_t OADJ_F = (size_t)2 * 4 * 128;                 // [group][4][128] (3 outputs used)
   static constexpr size_t DUMMY_F = 64 * 8;                             // sink of the lanes that own no accumulator slot
-  static size_t bytes(int L) { return X_BYTES + (OADJ_F + DUMMY_F + 3 * HP + (size_t)sg_total(HP, L)) * sizeof(float); }
+  static size_t bytes(int L) { return X_BYTES + (OADJ_F + DUMMY_F + 6 * HP + (size_t)sg_total(HP, L)) * sizeof(float); }
 };
 
 template <int HP, int TERMS>
@@ -42,16 +42,21 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #define PINN_SRING 2
 #endif
 #ifndef PINN_ABL
-#define PINN_ABL 0      // timing-only ablation switches (scripts/abl_build.py): 1 = no Z-bar spill, 4 = S quads loaded once per phase
+#define PINN_ABL 0      // timing-only ablation switches (scripts/abl_build.py): 1 = no Z-bar spill, 4 = S quads loaded once per phase,
+                        // 8 = G phase without its MFMAs (operands still fetched), 16 = E phase reduced to its barriers
 #endif
-  constexpr int RING = PINN_SRING, WPRE = RING - 1;
+#ifndef PINN_BDS
+#define PINN_BDS 1      // B fragments (image reads) requested this many column-block steps ahead
+#endif
+  constexpr int RING = PINN_SRING, WPRE = RING - 1, BD = PINN_BDS;
   constexpr size_t PLQ = (size_t)(HP / 4) * PPL;          // f32x4 per plane of S / Z-bar
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* const X = ldsb;
   float* const oadjL = reinterpret_cast<float*>(ldsb + G::X_BYTES);         // [2][4][128]
   float* const dummy = oadjL + G::OADJ_F;
   float* const woutL = dummy + G::DUMMY_F;                                   // [3][HP]
-  float* const sgacc = woutL + 3 * HP;                                       // [sg_total]
+  float* const w0L = woutL + 3 * HP;                                         // [w0x | w0y | b0][HP]
+  float* const sgacc = w0L + 3 * HP;                                         // [sg_total]
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, w = wave & 3;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   const int SG = sg_total(HP, L);
   float* const oadjG = oadjL + (size_t)grp * 4 * 128;
   for (int i = tid; i < SG; i += 2 * GT) sgacc[i] = 0.f;
-  for (int i = tid; i < 3 * HP; i += 2 * GT) woutL[i] = P[prep_wout(HP, L) + i];
+  for (int i = tid; i < 3 * HP; i += 2 * GT) { woutL[i] = P[prep_wout(HP, L) + i]; w0L[i] = P[prep_w0x(HP) + i]; }
   for (int i = tid; i < (int)G::DUMMY_F; i += 2 * GT) dummy[i] = 0.f;
   float dbo[3] = {0.f, 0.f, 0.f};
 
@@ -76,6 +81,49 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   f32x16 acc[2][4];
   u32x2 st[2][4][2];
   bool have_parked = false;
+#ifdef PINN_STAMP
+  // diagnostic build only: s_memtime stamps of workgroup 0, wave 0 of each group, third pair, into the ebar buffer
+  long long* const stamp = reinterpret_cast<long long*>(a.ebar) + grp * 1024;
+  bool stamp_on = false;
+  int nstamp = 0;
+#define STAMP() do { if (stamp_on && nstamp < 1024) { if (lane0 == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+
+  // saved-activation quads in flight: requested SQ quads ahead of their use, the first SQ of a phase already during the
+  // LAST quarter of the G phase before it (whose registers are idle): no phase starts by waiting out the HBM latency
+  constexpr int SQ = 2;
+  f32x4 sq[SQ + 1][4];
+  auto quad_o = [&](int qq, int h) { return qbase(qq >> 2, qq & 3) + 4 * h; };      // qq = 4 fb + g in processing order
+  auto sload = [&](const float* Sl, int qq, int col, int h) {
+    const int o = quad_o(qq, h);
+    const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      sq[qq % (SQ + 1)][p] = __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+  };
+  auto s_layer = [&](int tile, int l) {      // the dummy partner of an odd tile count reads tile 0's (finite) S
+    return a.S + ((size_t)(tile < a.ntiles ? tile : 0) * L + l) * ((size_t)HP * COLS);
+  };
+#ifndef PINN_COMMIT
+#define PINN_COMMIT 2
+#endif
+#ifndef PINN_XPRE
+#define PINN_XPRE 3     // cross-phase prefetch: 1 = S quads of E_{l-1} during G_l, 2 = first weight k-steps of G_l during E_l
+#endif
+  // weight-fragment ring of the G phases [feature block][k-step % RING]; lives across phases (PINN_XPRE & 2)
+  u32x4 wh[2][RING], wl[2][RING];
+  typedef __attribute__((address_space(1))) u32x4 gu32x4;
+  auto wload = [&](int l, int s, int wlane) {
+    const gu32x4* const wf = reinterpret_cast<const gu32x4*>(pin_base(reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l))));
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+      wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+      if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+    }
+  };
+  auto w_lane = [&](int col, int h) { return ((2 * (col >> 4) + (w >> 1)) * KS) * 64 + 16 * (w & 1) + (col & 15) + 32 * h; };
 
   auto dump = [&](int fb, int g0, int col, int h) {
 #pragma unroll
@@ -90,55 +138,60 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   };
 
   // ---------------- G phase: acc <- W_l^T x z-bar image, region q in quarter q ----------------
-  auto gphase = [&](int l) {
+  auto gphase = [&](int l, int tile, auto PRE_S) {
+    constexpr bool pre_s = decltype(PRE_S)::value;      // (layer 0 is recomputed, not read: nothing to request before E_0)
     PHASE_LANE_B();
-    const int wlane = ((2 * (col >> 4) + (w >> 1)) * KS) * 64 + 16 * (w & 1) + (col & 15) + 32 * h;
-    typedef __attribute__((address_space(1))) u32x4 gu32x4;
-    const gu32x4* const wf = reinterpret_cast<const gu32x4*>(pin_base(reinterpret_cast<const u32x4*>(P + prep_wtf(HP, l))));
-    u32x4 wh[2][RING], wl[2][RING], bh[2], bo[2];
-    auto wload = [&](int s) {
-#pragma unroll
-      for (int fb = 0; fb < 2; ++fb) {
-        wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-      }
-    };
+    const int wlane = w_lane(col, h);
+    u32x4 bh[BD + 1], bo[BD + 1];
+    const float* const Snext = s_layer(tile, l - 1);
     auto bload = [&](int u) {
       const int s = u >> 2, j = u & 3;
       const int off = XI::chunk_off(col, 2 * s + h);
-      bh[u & 1] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
-      if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
+      bh[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
+      if (TERMS == 3) bo[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
     };
+    if (!(PINN_XPRE & 2)) {
 #pragma unroll
-    for (int s = 0; s < WPRE; ++s) wload(s);
+      for (int s = 0; s < WPRE; ++s) wload(l, s, wlane);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      STAMP();
       if (q == 0 && have_parked) dump(1, 2, col, h);
-      bload(16 * q);
+#pragma unroll
+      for (int d = 0; d < BD; ++d) bload(16 * q + d);
 #pragma unroll
       for (int u = 16 * q; u < 16 * q + 16; ++u) {
         const int s = u >> 2, j = u & 3;
-        if (j == 0 && s + WPRE < KS) wload(s + WPRE);
-        if ((u & 15) != 15) bload(u + 1);
+        if (j == 0 && s + WPRE < KS) wload(l, s + WPRE, wlane);
+        // the next E phase's first saved-activation quads: younger than every weight request of this phase
+        if ((PINN_XPRE & 1) && pre_s && u >= 4 * (KS - WPRE) && u < 4 * (KS - WPRE) + SQ) sload(Snext, u - 4 * (KS - WPRE), col, h);
+        if ((u & 15) + BD <= 15) bload(u + BD);
+        if (PINN_ABL & 8) {
+          asm volatile("" :: "v"(bh[u % (BD + 1)]), "v"(bo[u % (BD + 1)]), "v"(wh[0][s % RING]), "v"(wh[1][s % RING]),
+                       "v"(wl[0][s % RING]), "v"(wl[1][s % RING]));
+          continue;
+        }
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) {
           if (s == 0) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u & 1], zero) : mfma_bf16(wh[fb][0], bh[u & 1], zero);
+            acc[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u % (BD + 1)], zero) : mfma_bf16(wh[fb][0], bh[u % (BD + 1)], zero);
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wl[fb][0], bh[u & 1], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wh[fb][0], bh[u & 1], acc[fb][j]);
+              acc[fb][j] = mfma_bf16(wl[fb][0], bh[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = mfma_bf16(wh[fb][0], bh[u % (BD + 1)], acc[fb][j]);
             }
           } else {
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u & 1], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u & 1], acc[fb][j]);
+              acc[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u % (BD + 1)], acc[fb][j]);
             }
-            acc[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u & 1], acc[fb][j]);
+            acc[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u % (BD + 1)], acc[fb][j]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      STAMP();
       __syncthreads();
     }
     have_parked = false;
@@ -157,16 +210,26 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
     }
   };
 
+  auto idle_ = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __syncthreads();
+  };
   // ---------------- E phase: tanh adjoint of layer lE of this group's tile ----------------
   // EK: 0 = last hidden layer L-1 (a-stream adjoints from the output adjoints on the VALU, dW_out), 1 = layer L-2..1,
   //     2 = layer 0 (dW_0; no image, nothing parked, no spill; the NEXT tile's output adjoints ride in quarter 3).
   auto ephase = [&](auto EKIND, int lE, int tileE, float pxE, float pyE, int next_tile, float& pxN, float& pyN) {
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool first = EK == 0, last = EK == 2;
-    constexpr int SQ = 2;                                 // S quads in flight ahead of the one being processed
     PHASE_LANE_B();
-    const int tileS = tileE < a.ntiles ? tileE : 0;       // the dummy partner of an odd tile count reads tile 0's (finite) S
-    const float* const Sl = a.S + ((size_t)tileS * L + lE) * ((size_t)HP * COLS);
+    if (PINN_ABL & 16) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[fb][j]));
+      idle_();
+      return;
+    }
+    const float* const Sl = s_layer(tileE, lE);
     float* const Zl = a.Zb + ((size_t)tileE * L + lE) * ((size_t)HP * COLS);
     float oc[3][4];
     if (first) {
@@ -175,30 +238,46 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) oc[c][s] = oadjG[c * COLS + s * PPL + col];
     }
-    f32x4 sq[SQ + 1][4];
-    auto quad_o = [&](int qq) { return qbase(qq >> 2, qq & 3) + 4 * h; };      // qq = 4 fb + g in processing order
-    auto sload = [&](int qq) {
-      const int o = quad_o(qq);
-      const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        sq[qq % (SQ + 1)][p] = __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
-    };
     auto commit = [&](int base, int o4, float v) {        // lanes col < 4 of each half own feature o4 + col (reduce_util.h)
       float* p = col < 4 ? &sgacc[base + o4 + (col & 3)] : &dummy[wave * 64 + lane];
+#if PINN_COMMIT == 0
       lds_add(p, v);
+#elif PINN_COMMIT == 1
+      if (col < 4) lds_add(p, v);
+#else
+      *p += v;          // plain read-modify-write: only the owning wave ever touches the slot, in program order
+#endif
     };
+    if (!last && (first || !(PINN_XPRE & 1))) {      // (every other E phase follows a G phase, which has requested them)
 #pragma unroll
-    for (int qq = 0; qq < ((PINN_ABL & 4) ? SQ + 1 : SQ); ++qq) sload(qq);
+      for (int qq = 0; qq < SQ; ++qq) sload(Sl, qq, col, h);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      STAMP();
       if (q > 0 && !last) dump((q - 1) >> 1, 2 * ((q - 1) & 1), col, h);
       const int fb = q >> 1;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int g = 2 * (q & 1) + k, qq = 2 * q + k, o = quad_o(qq);
-        if (qq + SQ < 8 && !(PINN_ABL & 4)) sload(qq + SQ);
-        const f32x4 (&sc)[4] = sq[qq % (SQ + 1)];
+        const int g = 2 * (q & 1) + k, qq = 2 * q + k, o = quad_o(qq, h);
+        if (!last && qq + SQ < 8 && !(PINN_ABL & 4)) sload(Sl, qq + SQ, col, h);
+        // first weight k-steps of the G phase that follows (its first MFMA would otherwise wait out an L2 round trip)
+        if ((PINN_XPRE & 2) && !last && qq == 7) {
+#pragma unroll
+          for (int s = 0; s < WPRE; ++s) wload(lE, s, w_lane(col, h));
+        }
+        f32x4 sc[4];
+        if (last) {
+          // layer 0 is not spilled (fwd_bf16_split.hip): same two FMAs and tanh as the forward, bit for bit
+          const f32x4 wx4 = *reinterpret_cast<const f32x4*>(w0L + o), wy4 = *reinterpret_cast<const f32x4*>(w0L + HP + o);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc[0][e] = fast_tanh(fmaf(wx4[e], pxE, fmaf(wy4[e], pyE, b4[e])));
+          sc[1] = wx4; sc[2] = wy4; sc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) sc[p] = sq[qq % (SQ + 1)][p];
+        }
         f32x4 zq[4], wov[3], dwv[2], wo4[3];
         if (first) {
 #pragma unroll
@@ -247,6 +326,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
           commit(sg_w0y(HP, L), o4, sum_cols4<32>(dwv[1][0], dwv[1][1], dwv[1][2], dwv[1][3], lane));
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP();
         if (!last) {
           const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
 #pragma unroll
@@ -259,6 +339,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if (last && q == 3 && next_tile >= 0) seeds(next_tile, pxN, pyN);      // the group's next tile: its output adjoints
+      STAMP();
       __syncthreads();
     }
     have_parked = !last;
@@ -280,13 +361,16 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   if (grp == 1) idle();
   for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
     const int tile = 2 * pair + grp;
+#ifdef PINN_STAMP
+    stamp_on = blockIdx.x == 0 && w == 0 && pair == (int)blockIdx.x + 2 * (int)gridDim.x;
+#endif
     const int next_tile = pair + (int)gridDim.x < npairs ? 2 * (pair + (int)gridDim.x) + grp : -1;
     ephase(K0{}, L - 1, tile, px, py, -1, pxN, pyN);
     for (int l = L - 1; l >= 2; --l) {
-      gphase(l);
+      gphase(l, tile, std::true_type{});
       ephase(K1{}, l - 1, tile, px, py, -1, pxN, pyN);
     }
-    gphase(1);
+    gphase(1, tile, std::false_type{});
     ephase(K2{}, 0, tile, px, py, next_tile, pxN, pyN);
     px = pxN; py = pyN;
   }

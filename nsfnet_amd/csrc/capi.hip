@@ -48,6 +48,7 @@ struct pinn_plan_s {
   long n;
   int streams, ntiles, npad;
   int grid_f, grid_b, groups;
+  int s0_skip;           // the sweeps do not spill layer 0 (role-split pair): dw_bf16 recomputes its activations
   int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
   int pipe_b;            // schedule of the reverse sweep; for 1 / 2 grid_b is the pair grid
   // workspace offsets in bytes
@@ -184,6 +185,11 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (sb == 1 && bwd_pipe_lds_bytes(HP, L) > 163840) sb = 0;
   p->pipe_f = sf < 0 || sf > 2 ? 0 : sf;
   p->pipe_b = sb < 0 || sb > 2 ? 0 : sb;
+  // The role-split sweeps do not spill layer 0 (its saved activations are one FMA pair and one tanh of the point: the
+  // reverse sweep and dw_bf16 recompute them), so they only come as a pair, and with the bf16 dW kernel; a request for
+  // one of them alone runs that sweep on schedule 1.
+  p->s0_skip = p->pipe_f == 2 && p->pipe_b == 2 && net->prec_dw;
+  if (!p->s0_skip) { if (p->pipe_f == 2) p->pipe_f = 1; if (p->pipe_b == 2) p->pipe_b = 1; }
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   if (env_int("PINN_VERBOSE", 0))
     fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, schedule fwd %d bwd %d\n",
@@ -273,12 +279,14 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   return 0;
 }
 
-static int run_dw_and_stash(pinn_plan_t plan, void* ws, hipStream_t s) {
+static int run_dw_and_stash(pinn_plan_t plan, void* ws, const float* prep, const float* x, const float* y, hipStream_t s) {
   DwArgs d;
+  memset(&d, 0, sizeof(d));
   d.S = WS(plan, off_S); d.Zb = WS(plan, off_Zb);
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
   d.configure = 0;
+  d.s0_skip = plan->s0_skip; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
   return dispatch_dw(plan, d, s);
 }
 
@@ -301,7 +309,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
     rc = dispatch_bwd(plan, a, (hipStream_t)stream);
     if (rc) return hipfail(rc, "pinn_residual_backward");
   }
-  if (phases & 2) rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
+  if (phases & 2) rc = run_dw_and_stash(plan, ws, prep, x, y, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_residual_backward(dW)") : 0;
 }
 
@@ -353,7 +361,7 @@ int pinn_value_backward(pinn_plan_t plan, void* ws, const float* prep,
   a.sg = WS(plan, off_sg);
   int rc = dispatch_bwd(plan, a, (hipStream_t)stream);
   if (rc) return hipfail(rc, "pinn_value_backward");
-  rc = run_dw_and_stash(plan, ws, (hipStream_t)stream);
+  rc = run_dw_and_stash(plan, ws, prep, x, y, (hipStream_t)stream);
   return rc ? hipfail(rc, "pinn_value_backward(dW)") : 0;
 }
 

@@ -38,8 +38,10 @@ __device__ __forceinline__ u32x2 tr_read(const lds_u8* p) {
 }
 
 // PPL = points per plane of a tile: 32 (128-column tiles) or 16 (64-column tiles)
-template <int HP, int NS, int TERMS, int PPL>
-__global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
+// REC: the activations are layer 0's and were not spilled (DwArgs::s0_skip) - recomputed from the point.  A template
+// parameter, not a run-time flag: the steady-state loop must stay one basic block (see below).
+template <int HP, int NS, int TERMS, int PPL, bool REC>
+__device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
   constexpr int CPT = PPL / 8;                 // 32-column chunks per tile
   constexpr size_t ABLK = (size_t)HP * 4 * PPL; // floats per (tile, layer) activation block
   using DI = DwImg<HP>;
@@ -69,9 +71,26 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
   // other buffer - that VALU / ds_write work can sit in the MFMA shadow (4 VALU per MFMA are free on gfx950,
   // and a partner wave's VALU does NOT overlap this wave's MFMAs: tests/micro/mfma_valu_*.hip) - and then
   // requests chunk ch+2 into the registers it has just freed.
+  // Layer-0 activations that the role-split forward did not spill (DwArgs::s0_skip): recomputed from the point with the
+  // forward's own two FMAs and tanh; the point travels in sr[0][0..1] instead of the four saved quads.
+  constexpr bool rec = REC;
+  f32x4 wx4 = {0.f, 0.f, 0.f, 0.f}, wy4 = wx4, b4 = wx4;
+  if (rec) {
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(a.prep + prep_w0x(HP));
+    wx4 = w0[og]; wy4 = w0[HP / 4 + og]; b4 = w0[2 * (HP / 4) + og];
+  }
   f32x4 zrA[4], srA[4];
   auto gload = [&](int ch, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
     const int tile = t0 + ch / CPT, c = ch % CPT;
+    if (rec) {
+      const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
+      const unsigned lo_ = (unsigned)(og * PPL + p);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) zr[s] = __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + lo_);
+      const int pt = tile * PPL + 8 * c + p;
+      sr[0][0] = pt < a.n ? a.x[pt] : 0.f; sr[0][1] = pt < a.n ? a.y[pt] : 0.f;
+      return;
+    }
     // (tile, layer, plane, chunk) bases are uniform: pinned to scalar registers, one 32-bit lane offset
     const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + 8 * c;
@@ -84,7 +103,15 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
   };
   auto lstore = [&](int buf, const f32x4 (&zr)[4], const f32x4 (&sr)[4]) {
     f32x4 av[4];
-    if (NS == 4) {
+    if (rec) {
+      const float px = sr[0][0], py = sr[0][1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = fast_tanh(fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e]))), zx = wx4[e], zy = wy4[e];
+        const float d1 = 1.f - t * t, d2 = -2.f * t * d1;
+        av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy);
+      }
+    } else if (NS == 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = sr[0][e], zx = sr[1][e], zy = sr[2][e], zd = sr[3][e];
@@ -188,6 +215,12 @@ __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
         int i = 32 * (wc * TN + n) + i32;
         slab[(size_t)o * HP + i] = acc[m][n][r];
       }
+}
+
+template <int HP, int NS, int TERMS, int PPL>
+__global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
+  if (NS == 4 && PPL == 32 && a.s0_skip && blockIdx.y == 0) dw_bf16_body<HP, NS, TERMS, PPL, NS == 4 && PPL == 32>(a);
+  else dw_bf16_body<HP, NS, TERMS, PPL, false>(a);
 }
 
 template <int HP>

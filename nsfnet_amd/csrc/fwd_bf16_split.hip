@@ -53,7 +53,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
   using XI = typename G::XI;
   constexpr int GT = HP, KS = HP / 16, PPL = 32, COLS = 128;      // GT: threads per group
 #ifndef PINN_ABL
-#define PINN_ABL 0      // timing-only ablation switches (scripts/abl_build.py): 1 = no S spill, 2 = weights loaded once per phase
+#define PINN_ABL 0      // timing-only ablation switches (scripts/abl_build.py): 1 = no S spill, 2 = weights loaded once per phase,
+                        // 8 = M phase without its MFMAs (operands still fetched), 16 = E phase reduced to its barriers,
+                        // 32 = no image writes, 64 = no tanh
 #endif
 #ifndef PINN_SRING
 #define PINN_SRING 2
@@ -94,19 +96,34 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
 
   f32x16 acc[2][4];                       // this wave's accumulators: [feature block][stream]
   u32x2 st[2][4][2];                      // parked epilogue output of one region: [quad][stream][hi | lo]
-  bool have_parked = false;               // (uniform) region-3 quads waiting for quarter 0 of the next M phase
 
-  auto dump = [&](int fb, int g0, int col, int h) {       // parked quads (fb, g0), (fb, g0 + 1) -> image
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int off = XI::chunk_off(col, qbase(fb, g0 + k) >> 3) + 8 * h;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = st[k][p][0];
-        if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = st[k][p][1];
-      }
-    }
+#ifdef PINN_STAMP
+  // diagnostic build only: s_memtime stamps of workgroup 0, wave 0 of each group, third pair, into the buffer passed as `e`
+  long long* const stamp = reinterpret_cast<long long*>(const_cast<float*>(a.e)) + grp * 1024;
+  bool stamp_on = false;
+  int nstamp = 0;
+#define STAMP() do { if (stamp_on && nstamp < 1024) { if (lane0 == 0) stamp[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
+  // parked quad (fb, g0 + k), stream p -> image.  The image writes are SPREAD over the phase that issues them (one
+  // stream per MFMA step / one quad per epilogue quad) instead of bursting right behind a barrier: a burst of 64 writes
+  // per CU sits in the LDS queue in front of the partner group's first B-fragment reads of the quarter (PINN_DUMP=0:
+  // the burst; forward 2.05 -> 1.63 ms without the writes when nothing else limits it)
+#ifndef PINN_DUMP
+#define PINN_DUMP 1
+#endif
+  auto dump_kp = [&](int fb, int g0, int k, int p, int col, int h) {
+    if (PINN_ABL & 32) { asm volatile("" :: "v"(st[k][p][0]), "v"(st[k][p][1])); return; }      // (timing only: no image writes)
+    const int off = XI::chunk_off(col, qbase(fb, g0 + k) >> 3) + 8 * h;
+    *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = st[k][p][0];
+    if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = st[k][p][1];
   };
+  auto dump_k = [&](int fb, int g0, int k, int col, int h) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dump_kp(fb, g0, k, p, col, h);
+  };
+  auto dump = [&](int fb, int g0, int col, int h) { dump_k(fb, g0, 0, col, h); dump_k(fb, g0, 1, col, h); };
 
   // ---------------- M phase: acc <- W_l x image, region q in quarter q ----------------
   auto mphase = [&](int l) {
@@ -134,13 +151,22 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
     for (int s = 0; s < ((PINN_ABL & 2) ? RING : WPRE); ++s) wload(s);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q == 0 && have_parked) dump(1, 2, col, h);        // region 3 of this tile's previous layer (free since the
-      bload(16 * q);                                        // partner group finished with it a phase ago)
+      STAMP();
+      // region 3 of this tile's previous layer is free since the partner group finished with it a phase ago, and is
+      // read here in quarter 3 only: written during quarter 0, one stream of a quad every other step
+      if (q == 0 && !PINN_DUMP) dump(1, 2, col, h);      // (every M phase follows an E phase that parked)
+      bload(16 * q);
 #pragma unroll
       for (int u = 16 * q; u < 16 * q + 16; ++u) {
         const int s = u >> 2, j = u & 3;
         if (j == 0 && s + WPRE < KS && !(PINN_ABL & 2)) wload(s + WPRE);
         if ((u & 15) != 15) bload(u + 1);
+        if (PINN_DUMP && q == 0 && (u & 1)) dump_kp(1, 2, u >> 3, (u >> 1) & 3, col, h);
+        if (PINN_ABL & 8) {
+          asm volatile("" :: "v"(bh[u & 1]), "v"(bo[u & 1]), "v"(wh[0][s % RING]), "v"(wh[1][s % RING]),
+                       "v"(wl[0][s % RING]), "v"(wl[1][s % RING]));
+          continue;
+        }
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) {
           if (s == 0) {
@@ -160,9 +186,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);      // requests stay where they are written (one k-step / one step ahead)
       }
+      STAMP();
       __syncthreads();
     }
-    have_parked = false;
   };
 
   // ---------------- E phase: chain rule of layer lE of this group's tile ----------------
@@ -172,6 +198,15 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool last = EK == 2, first = EK == 0;
     PHASE_LANE();
+    if (PINN_ABL & 16) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[fb][j]));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) __syncthreads();
+      return;
+    }
     float* const Sl = a.S + ((size_t)tileE * L + lE) * ((size_t)HP * COLS);
     const float* const bE = biasL + (size_t)lE * HP;
     float po[3][4];
@@ -186,6 +221,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      STAMP();
       // ---- the previous tile's point stage (output-layer bias + cross-wave sum, then residuals / loss) ----
       if (pstage_tile >= 0 && q == 0) {
         for (int idx = gtid; idx < 3 * COLS; idx += GT) {
@@ -199,7 +235,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
       if (pstage_tile >= 0 && pstage_tile < a.ntiles && q == 1)
         residual_point_stage<PPL, COLS>(a, outvG, pstage_tile, gtid, npad, lsum);
       // ---- region q - 1, parked in the previous quarter, is free now ----
-      if (q > 0 && !last) dump((q - 1) >> 1, 2 * ((q - 1) & 1), col, h);
+      if (q > 0 && !last && !PINN_DUMP) dump((q - 1) >> 1, 2 * ((q - 1) & 1), col, h);
       // ---- the two register quads of region q ----
       const int fb = q >> 1;
 #pragma unroll
@@ -223,7 +259,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
             z = acc_read_s(acc[fb][0][r]) + b4[e]; zx = acc_read_s(acc[fb][1][r]); zy = acc_read_s(acc[fb][2][r]);
             zd = acc_read_s(acc[fb][3][r]);
           }
-          const float t = fast_tanh(z);
+          const float t = (PINN_ABL & 64) ? z : fast_tanh(z);
           const float d1 = 1.f - t * t;
           const float d2 = -2.f * t * d1;
           av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
@@ -231,6 +267,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
+        STAMP();
+        // region q - 1, parked in the previous quarter, is free now: quad k leaves its registers just before they are refilled
+        if (PINN_DUMP && q > 0 && !last) dump_k((q - 1) >> 1, 2 * ((q - 1) & 1), k, col, h);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           if (!last) {
@@ -243,7 +282,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
               for (int e = 0; e < 4; ++e) po[c][p] = fmaf(wo[e], av[p][e], po[c][p]);
             }
           }
-          if (!(PINN_ABL & 1)) __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+          // (layer 0 is not spilled: t = tanh(w0x x + w0y y + b0), z_x = w0x, z_y = w0y, z_D = 0 cost the reverse sweep
+          // and the dW kernel one FMA pair and one tanh to recompute - a sixth of the spill at 6 layers)
+          if (!first && !(PINN_ABL & 1)) __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
           if (last) asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));   // (no sinking behind the loop)
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -257,9 +298,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
           for (int s = 0; s < 4; ++s)
             partG[(w * 12 + c * 4 + s) * 32 + col] = po[c][s] + __shfl_xor(po[c][s], 32, 64);
       }
+      STAMP();
       __syncthreads();
     }
-    have_parked = !last;
   };
   auto idle = [&]() {
 #pragma unroll
@@ -278,6 +319,9 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
   int prev_tile = -1;
   for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
     const int tile = 2 * pair + grp;
+#ifdef PINN_STAMP
+    stamp_on = blockIdx.x == 0 && w == 0 && pair == (int)blockIdx.x + 2 * (int)gridDim.x;
+#endif
     ephase(K0{}, 0, tile, prev_tile);
     for (int l = 1; l < L - 1; ++l) {
       mphase(l);

@@ -69,6 +69,10 @@ struct DwArgs {
   int ntiles, L, groups;
   float* slabs;          // [(L-1)][groups][HP*HP]
   int configure;         // see FwdArgs
+  // Layer-0 activations recomputed instead of read (the role-split sweeps do not spill them: they are one FMA and one
+  // tanh of the point, fwd_bf16_split.hip): the points, the prepared parameters (w0x | w0y | b0 lead them) and n.
+  int s0_skip;
+  const float* x; const float* y; const float* prep; int n;
 };
 
 struct ReduceSrc { const float* slabs; int groups; const float* sg; int nwg; };
