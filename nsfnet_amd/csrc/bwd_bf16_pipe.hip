@@ -155,11 +155,11 @@ __global__ __launch_bounds__(HP, 1) void bwd_pipe_kernel(BwdArgs a) {
     };
     // slot of the skinny-gradient accumulator owned by this lane after a transposing column sum (lanes col < 4 of
     // each half own feature ob + 8g + 4h + col); every other lane adds its (discarded) value to a private sink, so
-    // the update is one unconditional ds_add_f32: no branch splits the MFMA block
+    // the update is unconditional (a plain read-modify-write, reduce_util.h): no branch splits the MFMA block
     auto commit = [&](int base, int q, float v) {
       const int fb = q >> 2, g = q & 3, o = 32 * (fb * NW + w) + 8 * g + 4 * h + (col & 3);
       float* p = col < 4 ? &sgacc[base + o] : &dummy[w * 64 + lane_];
-      lds_add(p, v);
+      lds_rmw_add(p, v);
     };
     // The adjoint of register quad q = (fb, g) in EIGHT slices (one per 6-MFMA step): 0-3 = chain rule of element e,
     // 4-7 = stream p: write the parked quad of the other block into the free image half, split the new z-bar into

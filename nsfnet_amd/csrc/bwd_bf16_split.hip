@@ -106,9 +106,6 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   auto s_layer = [&](int tile, int l) {      // the dummy partner of an odd tile count reads tile 0's (finite) S
     return a.S + ((size_t)(tile < a.ntiles ? tile : 0) * L + l) * ((size_t)HP * COLS);
   };
-#ifndef PINN_COMMIT
-#define PINN_COMMIT 2
-#endif
 #ifndef PINN_XPRE
 #define PINN_XPRE 3     // cross-phase prefetch: 1 = S quads of E_{l-1} during G_l, 2 = first weight k-steps of G_l during E_l
 #endif
@@ -240,13 +237,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
     }
     auto commit = [&](int base, int o4, float v) {        // lanes col < 4 of each half own feature o4 + col (reduce_util.h)
       float* p = col < 4 ? &sgacc[base + o4 + (col & 3)] : &dummy[wave * 64 + lane];
-#if PINN_COMMIT == 0
-      lds_add(p, v);
-#elif PINN_COMMIT == 1
-      if (col < 4) lds_add(p, v);
-#else
-      *p += v;          // plain read-modify-write: only the owning wave ever touches the slot, in program order
-#endif
+      lds_rmw_add(p, v);      // (unconditional, the other lanes hit a sink: a plain read-modify-write costs the same for 8 lanes as for 64)
     };
     if (!last && (first || !(PINN_XPRE & 1))) {      // (every other E phase follows a G phase, which has requested them)
 #pragma unroll

@@ -54,7 +54,15 @@ __device__ __forceinline__ float sum_cols4(float v0, float v1, float v2, float v
 
 // sgacc[i] += v as ONE ds_add_f32 (no returned value, no read-modify-write round trip through registers and
 // its lgkmcnt wait).  Every accumulator slot is only ever updated by the wave that owns the feature, in program
-// order, so the sums stay deterministic.
+// order, so the sums stay deterministic.  Call it under an exec mask that leaves only the owning lanes active: the LDS
+// float atomic serialises over its ACTIVE lanes (tests/micro/mfma_partner_mix.hip: ~770 cycles per 64-lane
+// instruction with four waves issuing them) and holds the LDS pipeline meanwhile.
 __device__ __forceinline__ void lds_add(float* p, float v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The same update as a plain read-modify-write, for callers that run it on ALL lanes (non-owners on a per-lane sink, to
+// keep the epilogue branch-free): a ds_read / ds_write pair costs the LDS ~4 cycles each whatever the lane count.
+// (role-split reverse sweep at 6x256 / 360k points: 3.61 ms with the 64-lane atomic, 3.38 masked, 3.36 this; the
+// 8-wave kernels keep the masked atomic - there the exposed LDS round trip of this form costs more: bwd_bf16_wide
+// 21.5 -> 27.6 ms at 8x400.)
+__device__ __forceinline__ void lds_rmw_add(float* p, float v) { *p += v; }
