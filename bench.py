@@ -123,6 +123,8 @@ def pmc_lookup(kernel, prec, L, H, points):
 
 
 def time_kernel(fn, reps):
+    fn(); fn()                      # (steady state: the first launch after a pause pays the clock ramp)
+    torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record(); fn(); b.record()
