@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nsfnet_amd import build as B
 
+VARIANT_SOURCES = {"dw_bf16.hip"}      # recompiled per variant beside the pipelined / role-split sweeps
+
+
 def main():
     B.build()
     out = os.path.join(ROOT, "experiments", "abl")
@@ -17,9 +20,9 @@ def main():
         objs = []
         for src in B.SOURCES:
             o = os.path.join(B.OBJ, src.replace(".hip", ".o"))
-            if src in B.EXTRA_FLAGS:
+            if src in B.EXTRA_FLAGS or src in VARIANT_SOURCES:
                 o = os.path.join(out, "%s_%s.o" % (src.replace(".hip", ""), name))
-                cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS[src] + shlex.split(flags) + ["-c", os.path.join(B.CSRC, src), "-o", o]
+                cmd = [B._hipcc()] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + shlex.split(flags) + ["-c", os.path.join(B.CSRC, src), "-o", o]
                 subprocess.run(cmd, check=True)
             objs.append(o)
         lib = os.path.join(out, "lib_%s.so" % name)

@@ -57,6 +57,26 @@ def test_host_only_entry_points(lib):
     assert [lib.pinn_plan_kernel(p, k) for k in (0, 1, 2)] == [b"fwd_wide_kernel", b"bwd_wide_kernel", b"dw_wide_kernel"]
     assert lib.pinn_plan_kernel(q2, 0) == b"fwd_bf16_kernel" and lib.pinn_plan_kernel(p2, 3) is None
     lib.pinn_plan_destroy(p2)
+    # the role-split sweeps share a spill format without the layer-0 slot: they come as a pair (with the bf16 dW kernel);
+    # asked for on one sweep only, that sweep runs the pipelined schedule
+    import os
+    for env, want in (({"PINN_FWD_SCHED": "2", "PINN_BWD_SCHED": "0"}, [b"fwd_pipe_kernel", b"bwd_bf16_kernel"]),
+                      ({"PINN_FWD_SCHED": "1", "PINN_BWD_SCHED": "2"}, [b"fwd_pipe_kernel", b"bwd_pipe_kernel"]),
+                      ({"PINN_SCHED": "0"}, [b"fwd_bf16_kernel", b"bwd_bf16_kernel"])):
+        old = {k: os.environ.get(k) for k in ("PINN_SCHED", "PINN_FWD_SCHED", "PINN_BWD_SCHED")}
+        try:
+            for k in old:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            p3 = ctypes.c_void_p()
+            assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p3)) == 0
+            assert [lib.pinn_plan_kernel(p3, k) for k in (0, 1)] == want, env
+            lib.pinn_plan_destroy(p3)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
     lib.pinn_plan_destroy(q2)
     for handle in (p, q):
         assert lib.pinn_plan_destroy(handle) == 0
