@@ -12,7 +12,7 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, unsigned long long
   f32x16 acc[4];
   for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   bf16x8_t a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(1.0f + threadIdx.x * 1e-3f); b[i] = (__bf16)(0.5f + 0.01f * i); }
+  for (int i = 0; i < 8; ++i) { a[i] = (mode & 8) ? (__bf16)0.f : (__bf16)(1.0f + threadIdx.x * 1e-3f + 0.37f * i); b[i] = (mode & 8) ? (__bf16)0.f : (__bf16)(0.5f + 0.01f * i + threadIdx.x * 3e-3f); }
   float v[8];
   for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 0.001f + i;
   f32x4* g = gbuf + ((size_t)blockIdx.x * 4 + (w & 3)) * per_wave + lane;
@@ -65,5 +65,13 @@ int main() {
       double cyc = (double)h[wsel * 2], rt = (double)h[wsel * 2 + 1];
       printf("%-28s %8.2f ms  wave %d: %12.0f shader cycles in %10.0f x 10 ns  -> %7.1f MHz\n", names[mode], ms, wsel, cyc, rt, cyc / rt * 100.0);
     }
+  // the same MFMA stream on all-zero operands: is the clock under MFMA load a power effect?
+  for (int mode : {9, 11}) {
+    const int iters = 40000;
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, iters, d, sink, gbuf, per_wave);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[16]; (void)hipMemcpy(h, d, 128, hipMemcpyDeviceToHost);
+    printf("%-28s wave 0: %7.1f MHz\n", mode == 9 ? "MFMA on zeros" : "MFMA on zeros + VALU", (double)h[0] / (double)h[1] * 100.0);
+  }
   return 0;
 }
