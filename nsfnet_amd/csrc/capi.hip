@@ -172,8 +172,9 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   // Schedule of the hidden-256 bf16 sweeps in residual mode: 0 = 8-wave kernels (fwd_bf16 / bwd_bf16), 1 = one wave
   // per SIMD, two tiles per wave (fwd_bf16_pipe / bwd_bf16_pipe), 2 = two wave groups in opposite phases
   // (fwd_bf16_split / bwd_bf16_split).  $PINN_FWD_SCHED / $PINN_BWD_SCHED choose per sweep, $PINN_SCHED both.
-  // Default 2.  Round-2 measurements at 6x256 / 360k points (ms): forward 2.88 / 2.69 / 2.65, reverse sweep
-  // 3.78 / 3.73-3.88 / 3.72 - the three schedules end within 8 % of each other (DESIGN.md section 4 says why).
+  // Default 2.  Round-2 measurements at 6x256 / 360k points (ms): forward 2.84 / 2.65 / 2.47, reverse sweep
+  // 3.75 / 3.40 / 3.22 - the schedules end close to each other because all of them wait on the spill traffic
+  // (DESIGN.md section 4.3).
   const bool pipe_shape = HP == 256 && !wide && streams == 4 && L >= 2;
   const int sched_all = env_int("PINN_SCHED", 2);
   int sf = env_int("PINN_FWD_SCHED", sched_all), sb = env_int("PINN_BWD_SCHED", sched_all);

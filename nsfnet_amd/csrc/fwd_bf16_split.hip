@@ -8,7 +8,9 @@
 // v_mfma_f32_32x32x16_bf16 back to back keeps its 32 cycles per MFMA while its PARTNER wave's VALU stream runs at
 // 4.7 instructions per MFMA slot (78 % of its solo rate), and the partner's LDS / vector-memory instructions issue on
 // ports the MFMA wave does not use.  One wave alone cannot do that for itself (every instruction of a wave issues in
-// order: fwd_bf16_pipe.hip, one wave per SIMD, is issue-bound at ~45 cycles per MFMA).
+// order: fwd_bf16_pipe.hip, one wave per SIMD, is issue-bound at ~45 cycles per MFMA).  What the schedule does NOT
+// escape: the CU's one in-order vector-memory path - the M group's weight-fragment loads queue behind
+// the E group's S stores, which drain at the HBM rate, so the M quarters run 1.2-1.4x their solo time.
 //
 // So: 512 threads = two groups of four waves; waves w and w + 4 are SIMD partners.  Group 0 owns tile A, group 1 tile
 // B (32 points x 4 streams each); within a group wave w owns 64 features.  The groups run the SAME program one phase
@@ -125,30 +127,41 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
   };
   auto dump = [&](int fb, int g0, int col, int h) { dump_k(fb, g0, 0, col, h); dump_k(fb, g0, 1, col, h); };
 
+  // weight-fragment ring of the M phases [feature block][k-step % RING].  It lives across phases: the first WPRE k-steps
+  // of M_{l+1} are requested during the last quad of E_l (PINN_XPRE & 2), so no M phase opens with an L2 round trip.
+#ifndef PINN_XPRE
+#define PINN_XPRE 2
+#endif
+  u32x4 wh[2][RING], wl[2][RING];
+  typedef __attribute__((address_space(1))) u32x4 gu32x4;
+  // this wave's rows in the prepared weight image (32-row blocks b, lane slot r + 32 h): per-lane offset in u32x4
+  // units, plus fb * 4 * KS * 64 + s * 64 (uniform)
+  auto w_lane = [&](int col, int h) { return ((2 * (col >> 4) + (w >> 1)) * KS) * 64 + 16 * (w & 1) + (col & 15) + 32 * h; };
+  auto wload_l = [&](int l, int s, int wlane) {
+    const gu32x4* const wf = reinterpret_cast<const gu32x4*>(pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, l))));
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+      wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+      if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+    }
+  };
+
   // ---------------- M phase: acc <- W_l x image, region q in quarter q ----------------
   auto mphase = [&](int l) {
     PHASE_LANE();
-    // this wave's rows in the prepared weight image (32-row blocks b, lane slot r + 32 h): per-lane offset in u32x4
-    // units, plus fb * 4 * KS * 64 + s * 64 (uniform)
-    const int wlane = ((2 * (col >> 4) + (w >> 1)) * KS) * 64 + 16 * (w & 1) + (col & 15) + 32 * h;
-    typedef __attribute__((address_space(1))) u32x4 gu32x4;
-    const gu32x4* const wf = reinterpret_cast<const gu32x4*>(pin_base(reinterpret_cast<const u32x4*>(P + prep_wf(HP, l))));
-    u32x4 wh[2][RING], wl[2][RING], bh[2], bo[2];
-    auto wload = [&](int s) {
-#pragma unroll
-      for (int fb = 0; fb < 2; ++fb) {
-        wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-        if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-      }
-    };
+    const int wlane = w_lane(col, h);
+    u32x4 bh[2], bo[2];
+    auto wload = [&](int s) { wload_l(l, s, wlane); };
     auto bload = [&](int u) {
       const int s = u >> 2, j = u & 3;
       const int off = XI::chunk_off(col, 2 * s + h);
       bh[u & 1] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
       if (TERMS == 3) bo[u & 1] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
     };
+    if ((PINN_ABL & 2) || !(PINN_XPRE & 2)) {
 #pragma unroll
-    for (int s = 0; s < ((PINN_ABL & 2) ? RING : WPRE); ++s) wload(s);
+      for (int s = 0; s < ((PINN_ABL & 2) ? RING : WPRE); ++s) wload(s);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       STAMP();
@@ -241,6 +254,10 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int g = 2 * (q & 1) + k, o = qbase(fb, g) + 4 * h;
+        if ((PINN_XPRE & 2) && !(PINN_ABL & 2) && !last && q == 3 && k == 1) {      // first weight k-steps of M_{lE+1}
+#pragma unroll
+          for (int s = 0; s < WPRE; ++s) wload_l(lE + 1, s, w_lane(col, h));
+        }
         f32x4 av[4], sv[4];
         f32x4 b4, wx4, wy4;
         if (first) {

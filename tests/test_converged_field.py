@@ -34,3 +34,31 @@ def test_trained_ev_nsfnet_matches_dns(prec, bar, Re, dns, final, monkeypatch, t
     assert eu < bar and ev < bar, (eu, ev)
     if prec != "bf16":
         assert abs(eu - final) < 0.05 and abs(ev - final) < 0.05    # the run's own end-of-training report
+
+
+def test_config3_shape_run_approaches_dns(monkeypatch, tmp_path):
+    """The headline shape itself (BASELINE config 3's 6x256 net on 360 000 collocation points, ev flavour with the 4x40
+    entropy net, Re = 2000) trained by THIS engine in bf16x3 on the role-split kernels: six stages of the production
+    schedule at 0.21x (630 000 steps, 92 GPU-minutes on one MI355X, profiles/r02_convergence_ev_config3shape_re2000.jsonl:
+    55.8 -> 24.7 -> 16.1 -> 10.4 -> 7.8 -> 6.2 % and still falling).  Not the < 4 % of the full schedule - a fifth of it - so
+    the bars here are the run's own end-of-training report, and the flow topology (one primary vortex where the DNS has it)."""
+    monkeypatch.setenv("NSFNET_PRECISION", "bf16x3")
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "scripts"))
+    import flow_topology as ft
+    from nsfnet_amd import ev_pinn_solver as es, cavity_data as cavity
+    P = es.PysicsInformedNeuralNetwork(
+        Re=2000, layers=6, layers_1=4, hidden_size=256, hidden_size_1=40, N_f=1000, alpha_evm=0.002,
+        net_params=os.path.join(HERE, "golden", "trained", "ev_re2000_6x256_net.pth"),
+        net_params_1=os.path.join(HERE, "golden", "trained", "ev_re2000_6x256_evm.pth"))
+    star = cavity.EvDataLoader(N_f=1000).loading_evaluate_data(os.path.join(HERE, "golden", "dns", "cavity_Re2000_256.mat"))
+    eu, ev, ep = P.evaluate(*star)
+    assert abs(eu - 6.21) < 0.1 and abs(ev - 6.26) < 0.1, (eu, ev)
+    X, Y, U, V = ft.load_dns(os.path.join(HERE, "golden", "dns", "cavity_Re2000_256.mat"))
+    u, v = ft.predict_field("ev", os.path.join(HERE, "golden", "trained", "ev_re2000_6x256_net.pth"), X, Y, 6, 256, Re=2000.0)
+    t_net, t_dns = ft.topology(X, Y, u, v), ft.topology(X, Y, U, V)
+    assert abs(t_net["primary"]["x"] - t_dns["primary"]["x"]) < 0.03 and abs(t_net["primary"]["y"] - t_dns["primary"]["y"]) < 0.03, (
+        t_net["primary"], t_dns["primary"])
