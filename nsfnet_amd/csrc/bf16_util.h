@@ -30,6 +30,32 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
   lo[1] = pack_bf16(x2 - bf_lo_f(h1), x3 - bf_hi_f(h1));
 }
 
+// ---- 24-bit spill format of the role-split sweeps -------------------------------------------------------------------
+// The bf16x3 operand split consumes 16 significant bits of a value (bf16 hi + bf16 lo); the spilled activations and
+// z-adjoints are read back only to be split (MFMA operands) or to enter chain-rule products whose other factors are
+// bf16x3 GEMM outputs of that accuracy.  So they are spilled ROUNDED TO 24 BITS (sign, exponent, 15 mantissa bits:
+// relative error <= 2^-16): the sixteen values of a register quad (4 features x 4 streams) travel as THREE 16-byte
+// planes - top halves of streams 0-1, top halves of streams 2-3, third bytes of all four - instead of four fp32
+// planes: a quarter fewer vector-memory instructions and bytes with the same 1-KiB-per-wave-instruction coalescing.
+// (Measured first as separate 8-byte and 4-byte planes: the same bytes in TWICE the instructions was slower than
+// fp32 - the spill is bound by memory instructions through the CU's vector-memory path, not by HBM bytes.)
+// Round half up in magnitude on the integer image; v_perm_b32 moves the bytes.
+__device__ __forceinline__ void pack24(const f32x4& x, u32x2& hi, unsigned& lo) {
+  const unsigned r0 = __float_as_uint(x[0]) + 0x80u, r1 = __float_as_uint(x[1]) + 0x80u;
+  const unsigned r2 = __float_as_uint(x[2]) + 0x80u, r3 = __float_as_uint(x[3]) + 0x80u;
+  hi[0] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);      // (selector bytes 0-3: second operand, 4-7: first, 0x0c: zero)
+  hi[1] = __builtin_amdgcn_perm(r3, r2, 0x07060302u);
+  lo = __builtin_amdgcn_perm(r1, r0, 0x0c0c0501u) | __builtin_amdgcn_perm(r3, r2, 0x05010c0cu);
+}
+__device__ __forceinline__ f32x4 unpack24(const u32x2& hi, unsigned lo) {
+  f32x4 x;
+  x[0] = __uint_as_float(__builtin_amdgcn_perm(hi[0], lo, 0x0504000cu));
+  x[1] = __uint_as_float(__builtin_amdgcn_perm(hi[0], lo, 0x0706010cu));
+  x[2] = __uint_as_float(__builtin_amdgcn_perm(hi[1], lo, 0x0504020cu));
+  x[3] = __uint_as_float(__builtin_amdgcn_perm(hi[1], lo, 0x0706030cu));
+  return x;
+}
+
 // tanh for the bf16 modes: 1 - 2/(exp(2z)+1) on v_exp_f32 / v_rcp_f32 (both 1 ulp: abs. error
 // ~2e-7, far below the bf16x3 operand rounding); saturates correctly at +-inf.  The bare v_rcp_f32
 // matters: an IEEE 1/x costs 11 VALU instructions, a fifth of the whole chain-rule epilogue.

@@ -93,15 +93,21 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 
   // saved-activation quads in flight: requested SQ quads ahead of their use, the first SQ of a phase already during the
   // LAST quarter of the G phase before it (whose registers are idle): no phase starts by waiting out the HBM latency
-  constexpr int SQ = 2;
-  f32x4 sq[SQ + 1][4];
+#ifndef PINN_SQ
+#define PINN_SQ 2
+#endif
+  constexpr int SQ = PINN_SQ;
+  u32x4 sq[SQ + 1][3];       // 24-bit spill format (bf16_util.h pack24): hi16 of streams 0-1, of streams 2-3, lo8 of all four
   auto quad_o = [&](int qq, int h) { return qbase(qq >> 2, qq & 3) + 4 * h; };      // qq = 4 fb + g in processing order
   auto sload = [&](const float* Sl, int qq, int col, int h) {
     const int o = quad_o(qq, h);
     const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-      sq[qq % (SQ + 1)][p] = __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+    for (int k = 0; k < 3; ++k)
+      sq[qq % (SQ + 1)][k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + k * PLQ) + so));
+  };
+  auto unpack_plane = [&](const u32x4 (&pk)[3], int p) {
+    return unpack24(u32x2{pk[p >> 1][2 * (p & 1)], pk[p >> 1][2 * (p & 1) + 1]}, pk[2][p]);
   };
   auto s_layer = [&](int tile, int l) {      // the dummy partner of an odd tile count reads tile 0's (finite) S
     return a.S + ((size_t)(tile < a.ntiles ? tile : 0) * L + l) * ((size_t)HP * COLS);
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
           sc[1] = wx4; sc[2] = wy4; sc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
-          for (int p = 0; p < 4; ++p) sc[p] = sq[qq % (SQ + 1)][p];
+          for (int p = 0; p < 4; ++p) sc[p] = unpack_plane(sq[qq % (SQ + 1)], p);
         }
         f32x4 zq[4], wov[3], dwv[2], wo4[3];
         if (first) {
@@ -320,10 +326,17 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
         STAMP();
         if (!last) {
           const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
+          u32x4 pk[3];
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             split4(zq[p][0], zq[p][1], zq[p][2], zq[p][3], st[k][p][0], st[k][p][1]);
-            if (!(PINN_ABL & 1)) __builtin_nontemporal_store(zq[p], pin_base(reinterpret_cast<const f32x4*>(Zl) + p * PLQ) + so);
+            if (!(PINN_ABL & 1)) {      // 24-bit spill (bf16_util.h pack24): three 16-byte planes instead of four
+              u32x2 hi24; unsigned lo24;
+              pack24(zq[p], hi24, lo24);
+              pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
+              if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Zl) + (p >> 1) * PLQ) + so);
+              if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Zl) + 2 * PLQ) + so);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }

@@ -225,7 +225,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (ndev > 0) {     // (a host without a device can still size workspaces; it cannot launch anyway)
     FwdArgs fa; memset(&fa, 0, sizeof(fa)); fa.L = L; fa.configure = 1;
     BwdArgs ba; memset(&ba, 0, sizeof(ba)); ba.L = L; ba.configure = 1;
-    DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1;
+    DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1; da.s0_skip = p->s0_skip;
     int rc = dispatch_fwd(p, fa, nullptr);
     if (!rc && p->pipe_f) rc = dispatch_fwd(p, fa, nullptr, true);
     if (!rc) rc = dispatch_bwd(p, ba, nullptr);

@@ -40,7 +40,7 @@ __device__ __forceinline__ u32x2 tr_read(const lds_u8* p) {
 // PPL = points per plane of a tile: 32 (128-column tiles) or 16 (64-column tiles)
 // REC: the activations are layer 0's and were not spilled (DwArgs::s0_skip) - recomputed from the point.  A template
 // parameter, not a run-time flag: the steady-state loop must stay one basic block (see below).
-template <int HP, int NS, int TERMS, int PPL, bool REC>
+template <int HP, int NS, int TERMS, int PPL, bool REC, bool P24>
 __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
   constexpr int CPT = PPL / 8;                 // 32-column chunks per tile
   constexpr size_t ABLK = (size_t)HP * 4 * PPL; // floats per (tile, layer) activation block
@@ -80,7 +80,27 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
     wx4 = w0[og]; wy4 = w0[HP / 4 + og]; b4 = w0[2 * (HP / 4) + og];
   }
   f32x4 zrA[4], srA[4];
+  // P24: S and Z-bar arrive in the 24-bit spill format of the role-split sweeps (bf16_util.h pack24): THREE 16-byte
+  // planes per quad (hi16 of streams 0-1, hi16 of streams 2-3, lo8 of all four) instead of four, same plane geometry,
+  // same coalescing; unpacked at the head of the conversion.
+  u32x4 zpA[3], spA[3];
+  auto gload24 = [&](int ch) {
+    const int tile = t0 + ch / CPT, c = ch % CPT;
+    const unsigned lo_ = (unsigned)(og * PPL + p);
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zpA[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Zg + (size_t)k * (HP / 4) * PPL) + lo_));
+    if (rec) {
+      const int pt = tile * PPL + 8 * c + p;
+      srA[0][0] = pt < a.n ? a.x[pt] : 0.f; srA[0][1] = pt < a.n ? a.y[pt] : 0.f;
+    } else {
+      const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + 8 * c;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) spA[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Sg + (size_t)k * (HP / 4) * PPL) + lo_));
+    }
+  };
   auto gload = [&](int ch, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
+    if (P24) { gload24(ch); return; }
     const int tile = t0 + ch / CPT, c = ch % CPT;
     if (rec) {
       const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
@@ -101,7 +121,14 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
       sr[s] = __builtin_nontemporal_load(pin_base(Sg + (size_t)s * (HP / 4) * PPL) + lo_);
     }
   };
-  auto lstore = [&](int buf, const f32x4 (&zr)[4], const f32x4 (&sr)[4]) {
+  auto lstore = [&](int buf, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
+    if (P24) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        zr[s] = unpack24(u32x2{zpA[s >> 1][2 * (s & 1)], zpA[s >> 1][2 * (s & 1) + 1]}, zpA[2][s]);
+        if (!rec) sr[s] = unpack24(u32x2{spA[s >> 1][2 * (s & 1)], spA[s >> 1][2 * (s & 1) + 1]}, spA[2][s]);
+      }
+    }
     f32x4 av[4];
     if (rec) {
       const float px = sr[0][0], py = sr[0][1];
@@ -217,10 +244,11 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
       }
 }
 
-template <int HP, int NS, int TERMS, int PPL>
+// P24 = the plan's sweeps are the role-split pair (DwArgs::s0_skip): 24-bit spill format, layer 0 not spilled
+template <int HP, int NS, int TERMS, int PPL, bool P24>
 __global__ __launch_bounds__(HP * 2) void dw_bf16_kernel(DwArgs a) {
-  if (NS == 4 && PPL == 32 && a.s0_skip && blockIdx.y == 0) dw_bf16_body<HP, NS, TERMS, PPL, NS == 4 && PPL == 32>(a);
-  else dw_bf16_body<HP, NS, TERMS, PPL, false>(a);
+  if (P24 && blockIdx.y == 0) dw_bf16_body<HP, NS, TERMS, PPL, P24, P24>(a);
+  else dw_bf16_body<HP, NS, TERMS, PPL, false, P24>(a);
 }
 
 template <int HP>
@@ -234,15 +262,16 @@ size_t dw_bf16_lds_bytes(int HP) {
   }
 }
 
-template <int HP, int NS, int TERMS, int PPL>
+template <int HP, int NS, int TERMS, int PPL, bool P24 = false>
 static int launch_one(const DwArgs& a, hipStream_t s) {
+  if (!P24 && HP == 256 && NS == 4 && PPL == 32 && a.s0_skip) return launch_one<HP, NS, TERMS, PPL, HP == 256 && NS == 4 && PPL == 32>(a, s);
   size_t lds = lds_bytes_t<HP>();
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS, PPL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS, PPL, P24>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     return e == hipSuccess ? 0 : -(int)e;
   }
-  hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS, PPL>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
+  hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS, PPL, P24>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

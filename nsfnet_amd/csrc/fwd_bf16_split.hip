@@ -284,6 +284,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
+        u32x4 pk[3];      // the quad's 24-bit spill: hi16 of streams 0-1, hi16 of streams 2-3, lo8 of all four
         STAMP();
         // region q - 1, parked in the previous quarter, is free now: quad k leaves its registers just before they are refilled
         if (PINN_DUMP && q > 0 && !last) dump_k((q - 1) >> 1, 2 * ((q - 1) & 1), k, col, h);
@@ -301,7 +302,13 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
           }
           // (layer 0 is not spilled: t = tanh(w0x x + w0y y + b0), z_x = w0x, z_y = w0y, z_D = 0 cost the reverse sweep
           // and the dW kernel one FMA pair and one tanh to recompute - a sixth of the spill at 6 layers)
-          if (!first && !(PINN_ABL & 1)) __builtin_nontemporal_store(sv[p], pin_base(reinterpret_cast<const f32x4*>(Sl) + p * PLQ) + so);
+          if (!first && !(PINN_ABL & 1)) {      // 24-bit spill (bf16_util.h pack24): three 16-byte planes instead of four
+            u32x2 hi24; unsigned lo24;
+            pack24(sv[p], hi24, lo24);
+            pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
+            if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Sl) + (p >> 1) * PLQ) + so);
+            if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Sl) + 2 * PLQ) + so);
+          }
           if (last) asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));   // (no sinking behind the loop)
           __builtin_amdgcn_sched_barrier(0);
         }
