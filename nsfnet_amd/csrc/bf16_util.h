@@ -56,6 +56,18 @@ __device__ __forceinline__ f32x4 unpack24(const u32x2& hi, unsigned lo) {
   return x;
 }
 
+// a register quad's four planes <-> the three 16-byte planes of the spill (hi16 of planes 0-1, of planes 2-3, lo8 of all)
+__device__ __forceinline__ void pack24_quad(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3, u32x4 (&pk)[3]) {
+  u32x2 h; unsigned l;
+  pack24(x0, h, l); pk[0][0] = h[0]; pk[0][1] = h[1]; pk[2][0] = l;
+  pack24(x1, h, l); pk[0][2] = h[0]; pk[0][3] = h[1]; pk[2][1] = l;
+  pack24(x2, h, l); pk[1][0] = h[0]; pk[1][1] = h[1]; pk[2][2] = l;
+  pack24(x3, h, l); pk[1][2] = h[0]; pk[1][3] = h[1]; pk[2][3] = l;
+}
+__device__ __forceinline__ f32x4 unpack24_plane(const u32x4 (&pk)[3], int p) {
+  return unpack24(u32x2{pk[p >> 1][2 * (p & 1)], pk[p >> 1][2 * (p & 1) + 1]}, pk[2][p]);
+}
+
 // tanh for the bf16 modes: 1 - 2/(exp(2z)+1) on v_exp_f32 / v_rcp_f32 (both 1 ulp: abs. error
 // ~2e-7, far below the bf16x3 operand rounding); saturates correctly at +-inf.  The bare v_rcp_f32
 // matters: an IEEE 1/x costs 11 VALU instructions, a fifth of the whole chain-rule epilogue.

@@ -100,8 +100,16 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
             const int g = gq + 2 * hi;
             const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
             const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
-            f32x4 s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * PPL) + so), s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * PPL) + so);
-            f32x4 s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * PPL) + so), s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+            f32x4 s0, s1, s2, s3;
+            if (a.s24) {      // 24-bit three-plane spill (bf16_util.h pack24)
+              u32x4 pk[3];
+#pragma unroll
+              for (int k = 0; k < 3; ++k) pk[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(S4 + k * (HP / 4) * PPL) + so));
+              s0 = unpack24_plane(pk, 0); s1 = unpack24_plane(pk, 1); s2 = unpack24_plane(pk, 2); s3 = unpack24_plane(pk, 3);
+            } else {
+              s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * PPL) + so); s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+              s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * PPL) + so); s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+            }
             f32x4 z0, z1, z2, z3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -171,8 +179,15 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void bwd_bf16_wide_kernel
               *reinterpret_cast<u32x2*>(Xb + 3 * XI::PLANE * 2 + off) = vh;
               if (TERMS == 3) *reinterpret_cast<u32x2*>(Xb + XI::HALF * 2 + 3 * XI::PLANE * 2 + off) = vl;
               const f32x4* Z4 = reinterpret_cast<const f32x4*>(Zl);
-              __builtin_nontemporal_store(z0, pin_base(Z4 + 0 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z1, pin_base(Z4 + 1 * (HP / 4) * PPL) + so);
-              __builtin_nontemporal_store(z2, pin_base(Z4 + 2 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z3, pin_base(Z4 + 3 * (HP / 4) * PPL) + so);
+              if (a.s24) {
+                u32x4 pk[3];
+                pack24_quad(z0, z1, z2, z3, pk);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[k]), pin_base(Z4 + k * (HP / 4) * PPL) + so);
+              } else {
+                __builtin_nontemporal_store(z0, pin_base(Z4 + 0 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z1, pin_base(Z4 + 1 * (HP / 4) * PPL) + so);
+                __builtin_nontemporal_store(z2, pin_base(Z4 + 2 * (HP / 4) * PPL) + so); __builtin_nontemporal_store(z3, pin_base(Z4 + 3 * (HP / 4) * PPL) + so);
+              }
             }
           }
         } else {

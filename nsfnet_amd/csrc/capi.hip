@@ -48,6 +48,7 @@ struct pinn_plan_s {
   long n;
   int streams, ntiles, npad;
   int grid_f, grid_b, groups;
+  int s24w;              // wide bf16 residual plan (all three kernels bf16): 24-bit three-plane spill format
   int s0_skip;           // the sweeps do not spill layer 0 (role-split pair): dw_bf16 recomputes its activations
   int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
   int pipe_b;            // schedule of the reverse sweep; for 1 / 2 grid_b is the pair grid
@@ -190,6 +191,8 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   // reverse sweep and dw_bf16 recompute them), so they only come as a pair, and with the bf16 dW kernel; a request for
   // one of them alone runs that sweep on schedule 1.
   p->s0_skip = p->pipe_f == 2 && p->pipe_b == 2 && net->prec_dw;
+  // wide nets (hidden > 256), all three kernels in a bf16 mode, residual mode: the same 24-bit spill format
+  p->s24w = HP > 256 && streams == 4 && net->prec_fwd && net->prec_bwd && net->prec_dw;
   if (!p->s0_skip) { if (p->pipe_f == 2) p->pipe_f = 1; if (p->pipe_b == 2) p->pipe_b = 1; }
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   if (env_int("PINN_VERBOSE", 0))
@@ -225,7 +228,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   if (ndev > 0) {     // (a host without a device can still size workspaces; it cannot launch anyway)
     FwdArgs fa; memset(&fa, 0, sizeof(fa)); fa.L = L; fa.configure = 1;
     BwdArgs ba; memset(&ba, 0, sizeof(ba)); ba.L = L; ba.configure = 1;
-    DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1; da.s0_skip = p->s0_skip;
+    DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1; da.s0_skip = p->s0_skip; da.s24 = p->s24w;
     int rc = dispatch_fwd(p, fa, nullptr);
     if (!rc && p->pipe_f) rc = dispatch_fwd(p, fa, nullptr, true);
     if (!rc) rc = dispatch_bwd(p, ba, nullptr);
@@ -268,6 +271,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.prep = prep; a.S = save ? WS(plan, off_S) : nullptr;
   a.fld = fields; a.e = e; a.w = w; a.vtm = vis_t_minus; a.vis_used = vis_t_out;
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
+  a.s24 = plan->s24w;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
   const bool pipe = plan->pipe_f && save;
@@ -287,7 +291,7 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, const float* prep, const
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
   d.configure = 0;
-  d.s0_skip = plan->s0_skip; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
+  d.s0_skip = plan->s0_skip; d.s24 = plan->s24w; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
   return dispatch_dw(plan, d, s);
 }
 
@@ -304,6 +308,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   a.fld = fields; a.e = e; a.w = w; a.vis_used = vis_t;
   for (int k = 0; k < 4; ++k) a.coef_eq[k] = coef_eq4[k];
   a.inv_re = 1.0f / Re; a.scale = coord_scale; a.ebar = ebar_out;
+  a.s24 = plan->s24w;
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {

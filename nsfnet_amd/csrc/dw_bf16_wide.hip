@@ -21,7 +21,9 @@ __device__ __forceinline__ u32x2 tr_read(const lds_u8* p) {
 }
 }  // namespace
 
-template <int NS, int TERMS>
+// P24: S / Z-bar in the 24-bit three-plane spill format (DwArgs::s24; residual mode only) - a template parameter, the
+// steady-state loop must stay one basic block
+template <int NS, int TERMS, bool P24>
 __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
   constexpr int TM = 4, TN = 2, WN = 4, PPL = 16, COLS = 64, CPT = PPL / 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -53,11 +55,20 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   f32x4 zr[4], sr[4];
+  u32x4 zp[3], sp[3];
   auto gload = [&](int ch) {
     const int tile = t0 + ch / CPT, c = ch % CPT;
     const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * blk) + 8 * c;
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * blk) + 8 * c;
     const unsigned loz = (unsigned)(ogz * PPL + p), loa = (unsigned)(oga * PPL + p);
+    if (P24) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        zp[k] = vz ? __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Zg + (size_t)k * (HP / 4) * PPL) + loz)) : u32x4{0u, 0u, 0u, 0u};
+        sp[k] = va ? __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Sg + (size_t)k * (HP / 4) * PPL) + loa)) : u32x4{0u, 0u, 0u, 0u};
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       zr[s] = vz ? __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + loz) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -65,6 +76,10 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
     }
   };
   auto lstore = [&](int buf) {
+    if (P24) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { zr[s] = unpack24_plane(zp, s); sr[s] = unpack24_plane(sp, s); }
+    }
     f32x4 av[4];
     if (NS == 4) {
 #pragma unroll
@@ -173,15 +188,16 @@ __global__ __launch_bounds__(512) void dw_bf16_wide_kernel(DwArgs a, int HP) {
 
 size_t dw_bf16_wide_lds_bytes() { return DI::BYTES; }
 
-template <int NS, int TERMS>
+template <int NS, int TERMS, bool P24 = false>
 static int launch_one(int HP, const DwArgs& a, hipStream_t s) {
+  if (!P24 && NS == 4 && a.s24) return launch_one<NS, TERMS, NS == 4>(HP, a, s);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_wide_kernel<NS, TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_wide_kernel<NS, TERMS, P24>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)DI::BYTES);
     return e == hipSuccess ? 0 : -(int)e;
   }
   const int nblk = (HP / 32 + 7) / 8;
-  hipLaunchKernelGGL((dw_bf16_wide_kernel<NS, TERMS>), dim3(a.groups, a.L - 1, nblk * nblk), dim3(512), DI::BYTES, s, a, HP);
+  hipLaunchKernelGGL((dw_bf16_wide_kernel<NS, TERMS, P24>), dim3(a.groups, a.L - 1, nblk * nblk), dim3(512), DI::BYTES, s, a, HP);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }

@@ -135,10 +135,17 @@ __global__ __launch_bounds__(((HP / 32 + 1) / 2) * 64) void fwd_bf16_wide_kernel
             if (Sl) {
               const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
               const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
-              __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * PPL) + so);
-              __builtin_nontemporal_store(s1, pin_base(S4 + 1 * (HP / 4) * PPL) + so);
-              __builtin_nontemporal_store(s2, pin_base(S4 + 2 * (HP / 4) * PPL) + so);
-              __builtin_nontemporal_store(s3, pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+              if (a.s24) {      // 24-bit three-plane spill (bf16_util.h pack24): three instructions instead of four
+                u32x4 pk[3];
+                pack24_quad(s0, s1, s2, s3, pk);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[k]), pin_base(S4 + k * (HP / 4) * PPL) + so);
+              } else {
+                __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * PPL) + so);
+                __builtin_nontemporal_store(s1, pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+                __builtin_nontemporal_store(s2, pin_base(S4 + 2 * (HP / 4) * PPL) + so);
+                __builtin_nontemporal_store(s3, pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+              }
             }
           }
         } else {

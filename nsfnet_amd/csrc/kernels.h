@@ -45,6 +45,7 @@ struct FwdArgs {
   float* partials;       // [grid][PINN_NLOSS]
   int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
   int configure;         // 1: do not launch, only raise the kernel's dynamic-LDS limit (pinn_plan_create)
+  int s24;               // wide bf16 residual kernels: S / Z-bar in the 24-bit three-plane spill format (bf16_util.h pack24)
 };
 
 struct BwdArgs {
@@ -62,6 +63,7 @@ struct BwdArgs {
   const float* oadj;     // [4][npad]
   float* sg;             // [grid][sg_total]
   int configure;         // see FwdArgs
+  int s24;               // see FwdArgs
 };
 
 struct DwArgs {
@@ -72,6 +74,7 @@ struct DwArgs {
   // Layer-0 activations recomputed instead of read (the role-split sweeps do not spill them: they are one FMA and one
   // tanh of the point, fwd_bf16_split.hip): the points, the prepared parameters (w0x | w0y | b0 lead them) and n.
   int s0_skip;
+  int s24;               // see FwdArgs (dw_bf16_wide)
   const float* x; const float* y; const float* prep; int n;
 };
 
