@@ -225,7 +225,9 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // conversion VALU in its shadow
+      // conversion VALU in its shadow: 4 per MFMA (192 per chunk) cover the fp32 spill's conversion; the 24-bit spill's
+      // unpack adds 32 byte moves, and 5 per MFMA measured 2.60 against 2.71 ms (6-8: 2.60-2.66, 3: 2.70)
+      __builtin_amdgcn_sched_group_barrier(0x002, P24 ? 5 : 4, 0);
     }
     __syncthreads();
   }
