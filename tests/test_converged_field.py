@@ -39,10 +39,10 @@ def test_trained_ev_nsfnet_matches_dns(prec, bar, Re, dns, final, monkeypatch, t
 def test_config3_shape_run_matches_dns(monkeypatch, tmp_path):
     """The headline shape itself (BASELINE config 3's 6x256 net on 360 000 collocation points, ev flavour with the 4x40
     entropy net, Re = 2000) trained by THIS engine in bf16x3 on the role-split kernels: six stages of the production
-    schedule at 0.21x plus four repeats of the last one (1 050 000 steps, 152 GPU-minutes on one MI355X,
-    profiles/r02_convergence_ev_config3shape_re2000.jsonl: 55.8 -> 24.7 -> 16.1 -> 10.4 -> 7.8 -> 6.2 -> 5.2 -> 4.5 -> 4.0 -> 3.6 %;
-    the last 420 000 steps on the 24-bit-spill build, 8.2-8.6 ms/step) - inside the "< 4 %" the reference's README quotes, at
-    0.35 of the production schedule's steps.  The bars here are the run's own end-of-training report and the flow topology
+    schedule at 0.21x plus five repeats of the last one (1 155 000 steps, 167 GPU-minutes on one MI355X,
+    profiles/r02_convergence_ev_config3shape_re2000.jsonl: 55.8 -> 24.7 -> 16.1 -> 10.4 -> 7.8 -> 6.2 -> 5.2 -> 4.5 -> 4.0 -> 3.6 -> 3.3 %;
+    the last 525 000 steps on the 24-bit-spill builds, 8.1-8.6 ms/step) - inside the "< 4 %" the reference's README quotes, at
+    0.39 of the production schedule's steps.  The bars here are the run's own end-of-training report and the flow topology
     (one primary vortex where the DNS has it)."""
     monkeypatch.setenv("NSFNET_PRECISION", "bf16x3")
     monkeypatch.chdir(tmp_path)
@@ -58,7 +58,7 @@ def test_config3_shape_run_matches_dns(monkeypatch, tmp_path):
         net_params_1=os.path.join(HERE, "golden", "trained", "ev_re2000_6x256_evm.pth"))
     star = cavity.EvDataLoader(N_f=1000).loading_evaluate_data(os.path.join(HERE, "golden", "dns", "cavity_Re2000_256.mat"))
     eu, ev, ep = P.evaluate(*star)
-    assert abs(eu - 3.60) < 0.1 and abs(ev - 3.64) < 0.1, (eu, ev)
+    assert abs(eu - 3.29) < 0.1 and abs(ev - 3.33) < 0.1, (eu, ev)
     assert eu < 4.0 and ev < 4.0
     X, Y, U, V = ft.load_dns(os.path.join(HERE, "golden", "dns", "cavity_Re2000_256.mat"))
     u, v = ft.predict_field("ev", os.path.join(HERE, "golden", "trained", "ev_re2000_6x256_net.pth"), X, Y, 6, 256, Re=2000.0)
