@@ -8,8 +8,10 @@ MASTER_* in the environment) or plainly as above - then this process starts the 
 processes through torch.distributed.run on 127.0.0.1 (never exec), forwards rank 0's JSON line and exits with
 the children's code.
 
-Workloads = BASELINE.json `configs`, synthetic cell-centred uniform grids, PER-GPU share fixed
-(weak scaling), the reference's 2052 boundary points, alpha_b = 10, alpha_e = 1, Adam lr = 1e-3, seeded weights:
+Workloads = BASELINE.json `configs`, synthetic cell-centred uniform grids, the reference's 2052
+boundary points, alpha_b = 10, alpha_e = 1, Adam lr = 1e-3, seeded weights.  --scaling weak (default): the PER-GPU
+share below is fixed; --scaling strong: the TOTAL is fixed at 8 x that share (config 3: 2.88 M points)
+and split in equal row blocks over the N ranks (N must divide 8 x nx):
   --config 3 (default)  Re=2000 NSFnet, 6x256, 600x600 = 360 000 pts/GPU, bf16x3   <- the metric's configuration
   --config 2            Re=1000 NSFnet, 6x128, 400x300 = 120 000 pts/GPU, fp32
   --config 4            ev-NSFnet Re=4000, 6x256 + 4x40 entropy net, 250x1000 = 250 000 pts/GPU (1 M over 4 GPUs)
@@ -20,7 +22,7 @@ reduce (+ ONE RCCL all-reduce when N > 1) + Adam + parameter re-layout, i.e. the
 body (NSFnet/pinn_solver.py:250-254, ev-NSFnet/pinn_solver.py:456-472).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed live with HIP events on the launch
-stream; its `traffic` / `matrix_pipe_busy_pmc` come from profiles/r02_pmc.json (written by
+stream; its `traffic` / `matrix_pipe_busy_pmc` come from profiles/r03_pmc.json (written by
 scripts/pmc_summarize.py from separate rocprofv3 --pmc passes) and are null unless that file was measured on
 exactly this csrc/ (content hash) and this shape.  `sustained` = >= 2 s of back-to-back steps after the timed
 region (clock-settled figure).  `cpu_baseline` = the oracle's torch-autograd restatement of the reference step
@@ -45,7 +47,8 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md
 MFMA_PER_PRODUCT = {"fp32": 1, "bf16x3": 3, "bf16": 1}
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+STRONG_SHARES = 8      # --scaling strong: total = this many per-GPU shares of the config (2.88 M = 8 x 360 000)
 
 CONFIGS = {   # flavour, Re, L, H, (nx_local, ny), precision, nominal GPU count of the BASELINE config
     1: dict(flavour="nsfnet", re=100.0, layers=4, hidden=50, grid=(100, 100), precision="bf16x3", gpus=1),
@@ -79,6 +82,17 @@ def grid_block(nx_local, ny, rank, world):
     return X.reshape(-1).astype(np.float32), Y.reshape(-1).astype(np.float32)
 
 
+def local_rows(nx, scaling, world):
+    """Rows of the global grid one rank holds: weak = the config's per-GPU share, strong = an equal part of
+    STRONG_SHARES shares (config 3's net on 2.88 M points in total)."""
+    if scaling == "weak":
+        return nx
+    total = nx * STRONG_SHARES
+    if total % world:
+        raise SystemExit("bench.py: --scaling strong needs the rank count (%d) to divide %d grid rows" % (world, total))
+    return total // world
+
+
 def seeded_flat(L, H, n_out=3, seed=1234):
     """Default nn.Linear init of the reference FCNet under torch.manual_seed(seed), flattened
     in state_dict order (SURVEY.md 8d synthetic weights)."""
@@ -110,16 +124,16 @@ def csrc_hash():
 
 
 def pmc_lookup(kernel, prec, L, H, points):
-    """(traffic bytes per launch, matrix-pipe busy fraction, source) from profiles/r02_pmc.json or Nones."""
+    """(traffic bytes per launch, matrix-pipe busy fraction, source) from profiles/r03_pmc.json or Nones."""
     try:
         doc = json.load(open(PMC_JSON))
     except Exception:
         return None, None, None
     if doc.get("csrc_hash") != csrc_hash():
-        return None, None, "profiles/r02_pmc.json was measured on another csrc/ (%s)" % doc.get("csrc_hash")
+        return None, None, "profiles/r03_pmc.json was measured on another csrc/ (%s)" % doc.get("csrc_hash")
     for e in doc.get("entries", []):
         if (e["kernel_short"], e["precision"], e["layers"], e["hidden"], e["points"]) == (kernel, prec, L, H, points):
-            return e.get("traffic_bytes"), e.get("mfma_busy"), "profiles/r02_pmc.json:" + e["kernel"]
+            return e.get("traffic_bytes"), e.get("mfma_busy"), "profiles/r03_pmc.json:" + e["kernel"]
     return None, None, None
 
 
@@ -207,8 +221,10 @@ def parse_args():
     ap.add_argument("--precision", default=os.environ.get("NSFNET_PRECISION"),
                     help="bf16x3 (bf16 MFMA, hi/lo split, meets the 1e-4 loss-parity bar) | fp32 (f32-input MFMA, "
                          "bit-exact fp32) | bf16 (plain bf16 operands, fast mode, no parity claim); default per config")
-    ap.add_argument("--alt-precision", default=None, help="second mode reported in the 'alt' block ('' = skip; "
-                                                            "default: fp32 for config 3 at N = 1)")
+    ap.add_argument("--alt-precision", default=None, help="other modes reported in the 'alts' list, comma-separated ('' = "
+                                                            "skip; default: fp32,bf16 for config 3 at N = 1); 'alt' = the first")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the config's per-GPU share on every rank; strong: 8 shares in total, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
@@ -228,7 +244,8 @@ def parse_args():
         cfg["flavour"], cfg["layers"], cfg["hidden"], cfg["grid"], cfg["re"])
     args.config_name = "custom" if custom else "BASELINE configs[%d]" % (args.config - 1)
     if args.alt_precision is None:
-        args.alt_precision = "fp32" if (args.config == 3 and not custom and args.precision != "fp32") else ""
+        args.alt_precision = "fp32,bf16" if (args.config == 3 and not custom and args.scaling == "weak") else ""
+    args.alt_list = [p for p in args.alt_precision.split(",") if p and p != args.precision]
     if args.cpu_sample is None:     # ~10-20 s of CPU work whatever the net: scale the sample with 1 / P_w
         args.cpu_sample = max(1024, int(16384 * weight_count(6, 256) / weight_count(args.layers, args.hidden)))
         args.cpu_sample = min(args.cpu_sample, 65536)
@@ -244,8 +261,9 @@ def build_engine(eng, dev, args, precision, pg, world, rank):
     E.net.set_flat(seeded_flat(L, H))
     if ev:
         E.net_e.set_flat(seeded_flat(EV_NET[0], EV_NET[1], n_out=1, seed=4321))
-    x, y = grid_block(args.nx, args.ny, rank, world)
-    n_local = args.nx * args.ny
+    nxl = local_rows(args.nx, args.scaling, world)
+    x, y = grid_block(nxl, args.ny, rank, world)
+    n_local = nxl * args.ny
     E.set_collocation(x, y, n_global=n_local * world)
     xb, yb, ub, vb = cavity_boundary()
     nb = xb.size
@@ -307,6 +325,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     pg = None
+    backend = "none"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -322,7 +341,8 @@ def main():
     from nsfnet_amd import engine as eng
 
     L, H, Re = args.layers, args.hidden, args.re
-    n_local = args.nx * args.ny
+    nxl = local_rows(args.nx, args.scaling, world)
+    n_local = nxl * args.ny
     n_global = n_local * world
     E = build_engine(eng, dev, args, args.precision, pg, world, rank)
     lr = 1e-3
@@ -332,7 +352,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    log("%s: %s %dx%d, %d pts/GPU, world %d, %s" % (args.config_name, args.flavour, L, H, n_local, world, args.precision))
+    log("%s: %s %dx%d, %d pts/GPU (%s scaling), world %d, %s" % (args.config_name, args.flavour, L, H, n_local, args.scaling, world, args.precision))
     for i in range(args.warmup):
         E.step(lr)
         if i == 0:
@@ -377,33 +397,40 @@ def main():
         ev = args.flavour == "ev"
         out = dict(metric="collocation-pt NS-residual evals/sec, Re=%g %dx%d MLP" % (Re, L, H),
                    value=value, unit="collocation-pt residual evals/s", n_gpus=world, steps=args.steps,
-                   warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling="weak",
+                   warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling,
                    vs_baseline=None, dtype={"fp32": "f32", "bf16x3": "bf16x3 (bf16 MFMA, hi/lo split, f32 accumulate)",
                                             "bf16": "bf16"}.get(prec, prec), data="synthetic",
                    config=dict(workload="%s: %sRe=%g cavity, %dx%d tanh FCNet%s, %d collocation pts/GPU (%dx%d block of "
                                         "the cell-centred uniform grid) + 2052 BC pts, full Adam step, precision %s"
                                         % (args.config_name, "ev-NSFnet " if ev else "", Re, L, H,
-                                           " + %dx%d entropy net" % EV_NET if ev else "", n_local, args.nx, args.ny, prec),
+                                           " + %dx%d entropy net" % EV_NET if ev else "", n_local, nxl, args.ny, prec),
                                global_points=n_global, parallelism="dp%d" % world, final_loss=loss,
+                               # what moved the per-step all-reduce: "rccl" (torch backend "nccl" on ROCm) is the product
+                               # path; "gloo" only ever appears in single-GPU rehearsals of the rank logic
+                               backend={"nccl": "rccl"}.get(backend, backend),
                                csrc_hash=csrc_hash()),
                    roofline=roofline, sustained=sustained)
-        if args.alt_precision and args.alt_precision != prec and world == 1:
+        if args.alt_list and world == 1:
             del E
+            out["alts"] = []
+            for alt in args.alt_list:
+                torch.cuda.empty_cache()
+                E2 = build_engine(eng, dev, args, alt, None, 1, 0)
+                for _ in range(3):
+                    E2.step(lr)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                k2 = max(3, args.steps // 4)
+                for _ in range(k2):
+                    E2.step(lr)
+                torch.cuda.synchronize()
+                ms2 = 1e3 * (time.perf_counter() - t1) / k2
+                out["alts"].append(dict(precision=alt, value=n_global / (ms2 * 1e-3), ms_per_step=ms2, steps=k2,
+                                        final_loss=float(E2.loss_terms()["loss"]),
+                                        roofline=kernel_report(E2, args, alt, ms2, n_local, n_global)))
+                del E2
             torch.cuda.empty_cache()
-            E2 = build_engine(eng, dev, args, args.alt_precision, None, 1, 0)
-            for _ in range(3):
-                E2.step(lr)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            k2 = max(3, args.steps // 4)
-            for _ in range(k2):
-                E2.step(lr)
-            torch.cuda.synchronize()
-            ms2 = 1e3 * (time.perf_counter() - t1) / k2
-            out["alt"] = dict(precision=args.alt_precision, value=n_global / (ms2 * 1e-3), ms_per_step=ms2, steps=k2,
-                              roofline=kernel_report(E2, args, args.alt_precision, ms2, n_local, n_global))
-            del E2
-            torch.cuda.empty_cache()
+            out["alt"] = out["alts"][0]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.flavour, L, H, Re, args.cpu_sample)
         else:

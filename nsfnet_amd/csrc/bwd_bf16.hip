@@ -317,7 +317,7 @@ static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
   size_t lds = lds_bytes_t<HP, COLS>(a.L);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_bf16_kernel<HP, NS, TERMS, COLS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((bwd_bf16_kernel<HP, NS, TERMS, COLS>), dim3(grid), dim3(HP * 2), lds, s, a);

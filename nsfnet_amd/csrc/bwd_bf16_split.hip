@@ -18,9 +18,13 @@
 #include "reduce_util.h"
 
 __device__ __forceinline__ float acc_read_sb(float acc_elem) {      // just-in-time AGPR -> VGPR (see fwd_bf16_split.hip)
+#if !defined(PINN_ACCV) || PINN_ACCV      // default: the accumulators live in arch VGPRs (MFMA in VGPR form), the epilogue reads them in place
+  return acc_elem;
+#else      // PINN_ACCV=0: accumulators pinned to AGPRs, one v_accvgpr_read per element (round 2; same speed, profiles/r03_ablations.txt C)
   float v;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_elem));
   return v;
+#endif
 }
 
 template <int HP>
@@ -41,9 +45,17 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #ifndef PINN_SRING
 #define PINN_SRING 2
 #endif
+#ifndef PINN_ESB
+#define PINN_ESB 1      // see fwd_bf16_split.hip
+#endif
+#ifndef PINN_PRIO
+#define PINN_PRIO 0     // see fwd_bf16_split.hip
+#endif
+#define E_SB() do { if (PINN_ESB) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef PINN_ABL
 #define PINN_ABL 0      // timing-only ablation switches (scripts/abl_build.py): 1 = no Z-bar spill, 4 = S quads loaded once per phase,
-                        // 8 = G phase without its MFMAs (operands still fetched), 16 = E phase reduced to its barriers
+                        // 8 = G phase without its MFMAs (operands still fetched), 16 = E phase reduced to its barriers,
+                        // 2 = weights loaded once per phase, 128 / 256 = lo weight fragments for one feature block only / none, 512 = no Z-bar spill of the last hidden layer
 #endif
 #ifndef PINN_BDS
 #define PINN_BDS 1      // B fragments (image reads) requested this many column-block steps ahead
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
     return unpack24(u32x2{pk[p >> 1][2 * (p & 1)], pk[p >> 1][2 * (p & 1) + 1]}, pk[2][p]);
   };
   auto s_layer = [&](int tile, int l) {      // the dummy partner of an odd tile count reads tile 0's (finite) S
-    return a.S + ((size_t)(tile < a.ntiles ? tile : 0) * L + l) * ((size_t)HP * COLS);
+    return a.S + spill_off(tile < a.ntiles ? tile : 0, l, L, a.sl0, a.sblk, (size_t)HP * COLS);
   };
 #ifndef PINN_XPRE
 #define PINN_XPRE 3     // cross-phase prefetch: 1 = S quads of E_{l-1} during G_l, 2 = first weight k-steps of G_l during E_l
@@ -123,9 +135,11 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb) {
       wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-      if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+      if (TERMS == 3 && !(PINN_ABL & 256) && !((PINN_ABL & 128) && fb == 1))      // (timing only: 128 = one lo fragment for both feature blocks, 256 = none)
+        wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
     }
   };
+#define WLB_(fb, i) ((PINN_ABL & 256) ? wh[fb][i] : (PINN_ABL & 128) ? wl[0][i] : wl[fb][i])
   auto w_lane = [&](int col, int h) { return ((2 * (col >> 4) + (w >> 1)) * KS) * 64 + 16 * (w & 1) + (col & 15) + 32 * h; };
 
   auto dump = [&](int fb, int g0, int col, int h) {
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
   auto gphase = [&](int l, int tile, auto PRE_S) {
     constexpr bool pre_s = decltype(PRE_S)::value;      // (layer 0 is recomputed, not read: nothing to request before E_0)
     PHASE_LANE_B();
+    if (PINN_PRIO) __builtin_amdgcn_s_setprio(PINN_PRIO == 2 ? 2 : 0);
     const int wlane = w_lane(col, h);
     u32x4 bh[BD + 1], bo[BD + 1];
     const float* const Snext = s_layer(tile, l - 1);
@@ -153,9 +168,9 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
       bh[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + j * XI::PLANE * 2 + off);
       if (TERMS == 3) bo[u % (BD + 1)] = *reinterpret_cast<const u32x4*>(X + XI::HALF * 2 + j * XI::PLANE * 2 + off);
     };
-    if (!(PINN_XPRE & 2)) {
+    if ((PINN_ABL & 2) || !(PINN_XPRE & 2)) {
 #pragma unroll
-      for (int s = 0; s < WPRE; ++s) wload(l, s, wlane);
+      for (int s = 0; s < ((PINN_ABL & 2) ? RING : WPRE); ++s) wload(l, s, wlane);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -166,30 +181,31 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #pragma unroll
       for (int u = 16 * q; u < 16 * q + 16; ++u) {
         const int s = u >> 2, j = u & 3;
-        if (j == 0 && s + WPRE < KS) wload(l, s + WPRE, wlane);
+        if (j == 0 && s + WPRE < KS && !(PINN_ABL & 2)) wload(l, s + WPRE, wlane);
         // the next E phase's first saved-activation quads: younger than every weight request of this phase
         if ((PINN_XPRE & 1) && pre_s && u >= 4 * (KS - WPRE) && u < 4 * (KS - WPRE) + SQ) sload(Snext, u - 4 * (KS - WPRE), col, h);
         if ((u & 15) + BD <= 15) bload(u + BD);
         if (PINN_ABL & 8) {
           asm volatile("" :: "v"(bh[u % (BD + 1)]), "v"(bo[u % (BD + 1)]), "v"(wh[0][s % RING]), "v"(wh[1][s % RING]),
-                       "v"(wl[0][s % RING]), "v"(wl[1][s % RING]));
+                       "v"(WLB_(0, s % RING)), "v"(WLB_(1, s % RING)));
           continue;
         }
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) {
           if (s == 0) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u % (BD + 1)], zero) : mfma_bf16(wh[fb][0], bh[u % (BD + 1)], zero);
+            acc[fb][j] = TERMS == 3 ? MFMA_Q(0, wh[fb][0], bo[u % (BD + 1)], zero) : MFMA_Q(0, wh[fb][0], bh[u % (BD + 1)], zero);
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wl[fb][0], bh[u % (BD + 1)], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wh[fb][0], bh[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(1, WLB_(fb, 0), bh[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(0, wh[fb][0], bh[u % (BD + 1)], acc[fb][j]);
+              if (PINN_ABL_SHAPE16) acc[fb][j] = MFMA_Q(1, wh[fb][0], bo[u % (BD + 1)], acc[fb][j]);      // (timing only: initialise the other half too)
             }
           } else {
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u % (BD + 1)], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(s, wh[fb][s % RING], bo[u % (BD + 1)], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(s + 1, WLB_(fb, s % RING), bh[u % (BD + 1)], acc[fb][j]);
             }
-            acc[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u % (BD + 1)], acc[fb][j]);
+            acc[fb][j] = MFMA_Q(s, wh[fb][s % RING], bh[u % (BD + 1)], acc[fb][j]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool first = EK == 0, last = EK == 2;
     PHASE_LANE_B();
+    if (PINN_PRIO) __builtin_amdgcn_s_setprio(PINN_PRIO == 1 ? 2 : 0);
     if (PINN_ABL & 16) {
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb)
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
       return;
     }
     const float* const Sl = s_layer(tileE, lE);
-    float* const Zl = a.Zb + ((size_t)tileE * L + lE) * ((size_t)HP * COLS);
+    float* const Zl = a.Zb + spill_off(tileE, lE, L, a.sl0, a.sblk, (size_t)HP * COLS);
     float oc[3][4];
     if (first) {
 #pragma unroll
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
         const int g = 2 * (q & 1) + k, qq = 2 * q + k, o = quad_o(qq, h);
         if (!last && qq + SQ < 8 && !(PINN_ABL & 4)) sload(Sl, qq + SQ, col, h);
         // first weight k-steps of the G phase that follows (its first MFMA would otherwise wait out an L2 round trip)
-        if ((PINN_XPRE & 2) && !last && qq == 7) {
+        if ((PINN_XPRE & 2) && !(PINN_ABL & 2) && !last && qq == 7) {
 #pragma unroll
           for (int s = 0; s < WPRE; ++s) wload(lE, s, w_lane(col, h));
         }
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
             for (int c = 0; c < 3; ++c) wov[c][e] = oc[c][0] * t + oc[c][1] * ax + oc[c][2] * ay + oc[c][3] * ad;
           }
           if (last) { dwv[0][e] = zq[0][e] * pxE + zq[1][e]; dwv[1][e] = zq[0][e] * pyE + zq[2][e]; }
-          __builtin_amdgcn_sched_barrier(0);
+          E_SB();
         }
         // column sums of the four features at once (reduce_util.h); lane col == e of each half commits feature e
         const int o4 = o;     // (= qbase + 4h: the lane half's four features)
@@ -330,14 +347,14 @@ __global__ __launch_bounds__(2 * HP, 1) void bwd_split_kernel(BwdArgs a) {
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
             split4(zq[p][0], zq[p][1], zq[p][2], zq[p][3], st[k][p][0], st[k][p][1]);
-            if (!(PINN_ABL & 1)) {      // 24-bit spill (bf16_util.h pack24): three 16-byte planes instead of four
+            if (!(PINN_ABL & 1) && !((PINN_ABL & 512) && first)) {      // 24-bit spill (bf16_util.h pack24): three 16-byte planes instead of four
               u32x2 hi24; unsigned lo24;
               pack24(zq[p], hi24, lo24);
               pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
               if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Zl) + (p >> 1) * PLQ) + so);
               if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Zl) + 2 * PLQ) + so);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            E_SB();
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -402,7 +419,7 @@ static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
   const size_t lds = SplitBwdLds<HP>::bytes(a.L);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_split_kernel<HP, TERMS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((bwd_split_kernel<HP, TERMS>), dim3(grid), dim3(2 * HP), lds, s, a);

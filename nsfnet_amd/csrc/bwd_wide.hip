@@ -212,7 +212,7 @@ static int launch_one(const BwdArgs& a, int grid, hipStream_t s) {
   if (lds > 163840) return -1001;
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_wide_kernel<HP, NS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((bwd_wide_kernel<HP, NS>), dim3(grid), dim3(HP * 2), lds, s, a);

@@ -50,6 +50,8 @@ struct pinn_plan_s {
   int grid_f, grid_b, groups;
   int s24w;              // wide bf16 residual plan (all three kernels bf16): 24-bit three-plane spill format
   int s0_skip;           // the sweeps do not spill layer 0 (role-split pair): dw_bf16 recomputes its activations
+  int sl0; size_t sblk;  // compact spill geometry of the role-split plans (kernels.h spill_off); sblk = 0: classic layout
+  int stagger;           // $PINN_STAGGER, read once at plan creation
   int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
   int pipe_b;            // schedule of the reverse sweep; for 1 / 2 grid_b is the pair grid
   // workspace offsets in bytes
@@ -195,6 +197,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   p->s24w = HP > 256 && streams == 4 && net->prec_fwd && net->prec_bwd && net->prec_dw;
   if (!p->s0_skip) { if (p->pipe_f == 2) p->pipe_f = 1; if (p->pipe_b == 2) p->pipe_b = 1; }
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
+  p->stagger = env_int("PINN_STAGGER", 0);
   if (env_int("PINN_VERBOSE", 0))
     fprintf(stderr, "[pinn] plan: %ld pts, %d streams, HP %d, L %d, prec %d/%d/%d, wide %d, schedule fwd %d bwd %d\n",
             (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f, p->pipe_b);
@@ -216,9 +219,15 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   p->off_sg = off;       off = align_up(off + (size_t)p->grid_b * sg_total(HP, L) * 4, 256);
   p->off_slabs = off;    off = align_up(off + (size_t)(L - 1) * p->groups * HP * HP * 4, 256);
   const size_t ablk = (size_t)HP * (wide ? 64 : PINN_TILE_COLS);
+  // The role-split pair writes three 16-byte planes per register quad and no layer 0: its S and Z-bar are sized for
+  // exactly that, (L - 1) blocks of 3/4 of the classic HP x 128 floats per tile (5.5 instead of 8.9 GB each at
+  // 6x256 / 360 000 points).  Every other plan keeps the classic [tile][L][HP x columns] layout.
+  p->sl0 = p->s0_skip ? 1 : 0;
+  p->sblk = p->s0_skip ? ablk / 4 * 3 : 0;
+  const size_t spill_tile = p->s0_skip ? (size_t)(L - 1) * p->sblk : (size_t)L * ablk;      // floats per tile
   // (+1 tile: the pipelined kernels work on PAIRS of tiles; an odd count's dummy partner spills into this scratch block)
-  p->off_S = off;        off = align_up(off + (size_t)(p->ntiles + 1) * L * ablk * 4, 256);
-  p->off_Zb = off;       off = align_up(off + (size_t)(p->ntiles + 1) * L * ablk * 4, 256);
+  p->off_S = off;        off = align_up(off + (size_t)(p->ntiles + 1) * spill_tile * 4, 256);
+  p->off_Zb = off;       off = align_up(off + (size_t)(p->ntiles + 1) * spill_tile * 4, 256);
   p->bytes_all = off;
   // Raise the dynamic-LDS limit of the kernels this plan will launch, on the CURRENT device.  It is per-device
   // state of the HIP runtime and idempotent; doing it here, per plan, keeps the launch path free of cached
@@ -273,7 +282,8 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.inv_re = 1.0f / Re; a.vis_t0 = vis_t0; a.alpha_evm = alpha_evm; a.scale = coord_scale;
   a.s24 = plan->s24w;
   a.partials = WS(plan, off_partials);
-  a.stagger = plan->ntiles > 4 * plan->grid_f ? env_int("PINN_STAGGER", 0) : 0;
+  a.stagger = plan->ntiles > 4 * plan->grid_f ? plan->stagger : 0;
+  a.sl0 = plan->sl0; a.sblk = plan->sblk;
   const bool pipe = plan->pipe_f && save;
   int rc = dispatch_fwd(plan, a, (hipStream_t)stream, pipe);
   if (rc) return hipfail(rc, "pinn_residual_forward");
@@ -292,6 +302,7 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, const float* prep, const
   d.slabs = WS(plan, off_slabs);
   d.configure = 0;
   d.s0_skip = plan->s0_skip; d.s24 = plan->s24w; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
+  d.sl0 = plan->sl0; d.sblk = plan->sblk;
   return dispatch_dw(plan, d, s);
 }
 
@@ -309,6 +320,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   for (int k = 0; k < 4; ++k) a.coef_eq[k] = coef_eq4[k];
   a.inv_re = 1.0f / Re; a.scale = coord_scale; a.ebar = ebar_out;
   a.s24 = plan->s24w;
+  a.sl0 = plan->sl0; a.sblk = plan->sblk;
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {

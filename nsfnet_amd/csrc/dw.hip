@@ -133,7 +133,7 @@ static int launch_one(const DwArgs& a, hipStream_t s) {
   size_t lds = dw_lds_bytes(HP);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_kernel<HP, NS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((dw_kernel<HP, NS>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);

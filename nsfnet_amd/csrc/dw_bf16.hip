@@ -83,24 +83,30 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
   // P24: S and Z-bar arrive in the 24-bit spill format of the role-split sweeps (bf16_util.h pack24): THREE 16-byte
   // planes per quad (hi16 of streams 0-1, hi16 of streams 2-3, lo8 of all four) instead of four, same plane geometry,
   // same coalescing; unpacked at the head of the conversion.
-  u32x4 zpA[3], spA[3];
-  auto gload24 = [&](int ch) {
+  // Two raw sets (A, B): with the 24-bit format TWO chunks are in flight per workgroup (PINN_DWDEPTH 2) - one chunk in
+  // flight (48 KB per CU, 12 MB chip-wide) does not cover the HBM latency at the rate the MFMAs consume it.
+  struct Raw24 { u32x4 z[3], s[3]; float px, py; };
+  Raw24 rawA, rawB;
+  auto gload24 = [&](int ch, Raw24& R) {
     const int tile = t0 + ch / CPT, c = ch % CPT;
     const unsigned lo_ = (unsigned)(og * PPL + p);
-    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
+#ifndef PINN_ABL
+#define PINN_ABL 0      // timing-only (scripts/abl_build.py): 512 = the last hidden layer's Z-bar is not streamed (one resident block re-read)
+#endif
+    const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + spill_off(((PINN_ABL & 512) && l == a.L - 1) ? 0 : tile, l, a.L, a.sl0, a.sblk, ABLK)) + 8 * c;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) zpA[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Zg + (size_t)k * (HP / 4) * PPL) + lo_));
+    for (int k = 0; k < 3; ++k) R.z[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Zg + (size_t)k * (HP / 4) * PPL) + lo_));
     if (rec) {
       const int pt = tile * PPL + 8 * c + p;
-      srA[0][0] = pt < a.n ? a.x[pt] : 0.f; srA[0][1] = pt < a.n ? a.y[pt] : 0.f;
+      R.px = pt < a.n ? a.x[pt] : 0.f; R.py = pt < a.n ? a.y[pt] : 0.f;
     } else {
-      const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * ABLK) + 8 * c;
+      const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + spill_off(tile, l - 1, a.L, a.sl0, a.sblk, ABLK)) + 8 * c;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) spA[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Sg + (size_t)k * (HP / 4) * PPL) + lo_));
+      for (int k = 0; k < 3; ++k) R.s[k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(Sg + (size_t)k * (HP / 4) * PPL) + lo_));
     }
   };
   auto gload = [&](int ch, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
-    if (P24) { gload24(ch); return; }
+    if (P24) { gload24(ch, rawA); return; }
     const int tile = t0 + ch / CPT, c = ch % CPT;
     if (rec) {
       const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * ABLK) + 8 * c;
@@ -121,17 +127,17 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
       sr[s] = __builtin_nontemporal_load(pin_base(Sg + (size_t)s * (HP / 4) * PPL) + lo_);
     }
   };
-  auto lstore = [&](int buf, f32x4 (&zr)[4], f32x4 (&sr)[4]) {
+  auto lstore_r = [&](int buf, f32x4 (&zr)[4], f32x4 (&sr)[4], const Raw24& R) {
     if (P24) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        zr[s] = unpack24(u32x2{zpA[s >> 1][2 * (s & 1)], zpA[s >> 1][2 * (s & 1) + 1]}, zpA[2][s]);
-        if (!rec) sr[s] = unpack24(u32x2{spA[s >> 1][2 * (s & 1)], spA[s >> 1][2 * (s & 1) + 1]}, spA[2][s]);
+        zr[s] = unpack24(u32x2{R.z[s >> 1][2 * (s & 1)], R.z[s >> 1][2 * (s & 1) + 1]}, R.z[2][s]);
+        if (!rec) sr[s] = unpack24(u32x2{R.s[s >> 1][2 * (s & 1)], R.s[s >> 1][2 * (s & 1) + 1]}, R.s[2][s]);
       }
     }
     f32x4 av[4];
     if (rec) {
-      const float px = sr[0][0], py = sr[0][1];
+      const float px = P24 ? R.px : sr[0][0], py = P24 ? R.py : sr[0][1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float t = fast_tanh(fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e]))), zx = wx4[e], zy = wy4[e];
@@ -164,6 +170,7 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
       if (TERMS == 3) *reinterpret_cast<u32x2*>(row + 3 * DI::ARR) = lo;
     }
   };
+  auto lstore = [&](int buf, f32x4 (&zr)[4], f32x4 (&sr)[4]) { lstore_r(buf, zr, sr, rawA); };
   // transposed-read lane geometry: 16-lane group gq = lane>>4 -> feature half fb, k half (== h)
   const int li = lane & 15, fb = (lane >> 4) & 1, q = li >> 2, pp = li & 3;
   // (the two 4-row blocks of a fragment sit in rows q and q + 4 of their 8-row group: un-swizzle each with its row)
@@ -199,14 +206,57 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
           if (TERMS == 3) {
-            acc[m][n] = mfma_bf16(zh[m], al[n], acc[m][n]);
-            acc[m][n] = mfma_bf16(zl[m], ah[n], acc[m][n]);
+            acc[m][n] = MFMA_Q(ks, zh[m], al[n], acc[m][n]);
+            acc[m][n] = MFMA_Q(ks + 1, zl[m], ah[n], acc[m][n]);
           }
-          acc[m][n] = mfma_bf16(zh[m], ah[n], acc[m][n]);
+          acc[m][n] = MFMA_Q(ks, zh[m], ah[n], acc[m][n]);
         }
     }
   };
 
+#ifndef PINN_DWDEPTH
+#define PINN_DWDEPTH 1      // 2 = two chunks in flight (built and measured in round 3: no gain, profiles/r03_ablations.txt B)
+#endif
+  constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1);
+  auto interleave = [&]() {
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
+      // conversion VALU in its shadow: 4 per MFMA (192 per chunk) cover the fp32 spill's conversion; the 24-bit spill's
+      // unpack adds 32 byte moves, and 5 per MFMA measured 2.60 against 2.71 ms (6-8: 2.60-2.66, 3: 2.70)
+      __builtin_amdgcn_sched_group_barrier(0x002, P24 ? 5 : 4, 0);
+    }
+  };
+  if (P24 && PINN_DWDEPTH == 2) {
+    // chunk ch computes out of buffer ch & 1; raw set A carries the odd chunks, B the even ones (from chunk 2 on)
+    if (nch > 0) {
+      gload24(0, rawA);
+      lstore_r(0, zrA, srA, rawA);
+      gload24(nch > 1 ? 1 : 0, rawA);
+      gload24(nch > 2 ? 2 : nch - 1, rawB);
+    }
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 2 < nch; ch += 2) {
+      mfma_chunk(0);
+      lstore_r(1, zrA, srA, rawA);                           // chunk ch + 1
+      gload24(ch + 3 < nch ? ch + 3 : nch - 1, rawA);
+      interleave();
+      __syncthreads();
+      mfma_chunk(1);
+      lstore_r(0, zrA, srA, rawB);                           // chunk ch + 2
+      gload24(ch + 4 < nch ? ch + 4 : nch - 1, rawB);
+      interleave();
+      __syncthreads();
+    }
+    if (ch < nch) mfma_chunk(0);                             // (ch is even: its chunk sits in buffer 0)
+    if (ch + 1 < nch) {
+      lstore_r(1, zrA, srA, rawA);
+      __syncthreads();
+      mfma_chunk(1);
+    }
+    __syncthreads();
+  } else {
   if (nch > 0) {
     gload(0, zrA, srA);
     lstore(0, zrA, srA);
@@ -221,18 +271,12 @@ __device__ __forceinline__ void dw_bf16_body(const DwArgs& a) {
     mfma_chunk(buf);
     lstore(buf ^ 1, zrA, srA);
     gload(ch + 2 < nch ? ch + 2 : nch - 1, zrA, srA);
-    constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1);
-#pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // one MFMA
-      // conversion VALU in its shadow: 4 per MFMA (192 per chunk) cover the fp32 spill's conversion; the 24-bit spill's
-      // unpack adds 32 byte moves, and 5 per MFMA measured 2.60 against 2.71 ms (6-8: 2.60-2.66, 3: 2.70)
-      __builtin_amdgcn_sched_group_barrier(0x002, P24 ? 5 : 4, 0);
-    }
+    interleave();
     __syncthreads();
   }
   if (nch > 0) mfma_chunk((nch - 1) & 1);
   __syncthreads();
+  }
   float* slab = a.slabs + ((size_t)(l - 1) * a.groups + g) * HP * HP;
 #pragma unroll
   for (int m = 0; m < TM; ++m)
@@ -270,7 +314,7 @@ static int launch_one(const DwArgs& a, hipStream_t s) {
   size_t lds = lds_bytes_t<HP>();
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_kernel<HP, NS, TERMS, PPL, P24>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((dw_bf16_kernel<HP, NS, TERMS, PPL, P24>), dim3(a.groups, a.L - 1), dim3(HP * 2), lds, s, a);

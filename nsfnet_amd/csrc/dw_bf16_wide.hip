@@ -193,7 +193,7 @@ static int launch_one(int HP, const DwArgs& a, hipStream_t s) {
   if (!P24 && NS == 4 && a.s24) return launch_one<NS, TERMS, NS == 4>(HP, a, s);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_bf16_wide_kernel<NS, TERMS, P24>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)DI::BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   const int nblk = (HP / 32 + 7) / 8;

@@ -117,10 +117,10 @@ int launch_dw_wide(int HP, int NS, const DwArgs& a, hipStream_t s) {
   size_t lds = dw_wide_lds_bytes();
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wide_kernel<4>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_wide_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   dim3 grid(a.groups, a.L - 1, nblk * nblk);

@@ -369,7 +369,7 @@ static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   const size_t lds = PipeLds<HP>::bytes(a.L);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_pipe_kernel<HP, TERMS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_pipe_kernel<HP, TERMS>), dim3(grid), dim3(HP), lds, s, a);

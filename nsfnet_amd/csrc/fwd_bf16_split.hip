@@ -34,9 +34,13 @@
 // Just-in-time AGPR -> VGPR read of one accumulator element (keeps the register allocator from copying the whole
 // 128-register accumulator set into VGPRs at the top of the epilogue)
 __device__ __forceinline__ float acc_read_s(float acc_elem) {
+#if !defined(PINN_ACCV) || PINN_ACCV      // default: the accumulators live in arch VGPRs (MFMA in VGPR form), the epilogue reads them in place
+  return acc_elem;
+#else      // PINN_ACCV=0: accumulators pinned to AGPRs, one v_accvgpr_read per element (round 2; same speed, profiles/r03_ablations.txt C)
   float v;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc_elem));
   return v;
+#endif
 }
 
 template <int HP>
@@ -62,6 +66,13 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
 #ifndef PINN_SRING
 #define PINN_SRING 2
 #endif
+#ifndef PINN_ESB
+#define PINN_ESB 1      // 1: the epilogue's elements / planes are scheduled one at a time (sched_barrier between them); 0: the compiler may interleave them
+#endif
+#ifndef PINN_PRIO
+#define PINN_PRIO 0     // wave priority by phase: 1 = raised in the E phases, 2 = raised in the M phases (s_setprio; SIMD partners arbitrate by priority, then age)
+#endif
+#define E_SB() do { if (PINN_ESB) __builtin_amdgcn_sched_barrier(0); } while (0)
   constexpr int RING = PINN_SRING, WPRE = RING - 1;                // weight k-steps in the register ring / requested ahead
   constexpr size_t PLQ = (size_t)(HP / 4) * PPL;                   // f32x4 per S plane
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -142,13 +153,16 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb) {
       wh[fb][s % RING] = (wf + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
-      if (TERMS == 3) wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
+      if (TERMS == 3 && !(PINN_ABL & 256) && !((PINN_ABL & 128) && fb == 1))      // (timing only: 128 = one lo fragment for both feature blocks, 256 = none)
+        wl[fb][s % RING] = (wf + (size_t)(HP * HP / 8) + (size_t)fb * 4 * KS * 64 + s * 64)[wlane];
     }
   };
+#define WL_(fb, i) ((PINN_ABL & 256) ? wh[fb][i] : (PINN_ABL & 128) ? wl[0][i] : wl[fb][i])
 
   // ---------------- M phase: acc <- W_l x image, region q in quarter q ----------------
   auto mphase = [&](int l) {
     PHASE_LANE();
+    if (PINN_PRIO) __builtin_amdgcn_s_setprio(PINN_PRIO == 2 ? 2 : 0);
     const int wlane = w_lane(col, h);
     u32x4 bh[2], bo[2];
     auto wload = [&](int s) { wload_l(l, s, wlane); };
@@ -177,24 +191,25 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
         if (PINN_DUMP && q == 0 && (u & 1)) dump_kp(1, 2, u >> 3, (u >> 1) & 3, col, h);
         if (PINN_ABL & 8) {
           asm volatile("" :: "v"(bh[u & 1]), "v"(bo[u & 1]), "v"(wh[0][s % RING]), "v"(wh[1][s % RING]),
-                       "v"(wl[0][s % RING]), "v"(wl[1][s % RING]));
+                       "v"(WL_(0, s % RING)), "v"(WL_(1, s % RING)));
           continue;
         }
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) {
           if (s == 0) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[fb][j] = TERMS == 3 ? mfma_bf16(wh[fb][0], bo[u & 1], zero) : mfma_bf16(wh[fb][0], bh[u & 1], zero);
+            acc[fb][j] = TERMS == 3 ? MFMA_Q(0, wh[fb][0], bo[u & 1], zero) : MFMA_Q(0, wh[fb][0], bh[u & 1], zero);
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wl[fb][0], bh[u & 1], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wh[fb][0], bh[u & 1], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(1, WL_(fb, 0), bh[u & 1], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(0, wh[fb][0], bh[u & 1], acc[fb][j]);
+              if (PINN_ABL_SHAPE16) acc[fb][j] = MFMA_Q(1, wh[fb][0], bo[u & 1], acc[fb][j]);      // (timing only: initialise the other half too)
             }
           } else {
             if (TERMS == 3) {
-              acc[fb][j] = mfma_bf16(wh[fb][s % RING], bo[u & 1], acc[fb][j]);
-              acc[fb][j] = mfma_bf16(wl[fb][s % RING], bh[u & 1], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(s, wh[fb][s % RING], bo[u & 1], acc[fb][j]);
+              acc[fb][j] = MFMA_Q(s + 1, WL_(fb, s % RING), bh[u & 1], acc[fb][j]);
             }
-            acc[fb][j] = mfma_bf16(wh[fb][s % RING], bh[u & 1], acc[fb][j]);
+            acc[fb][j] = MFMA_Q(s, wh[fb][s % RING], bh[u & 1], acc[fb][j]);
           }
         }
         __builtin_amdgcn_sched_barrier(0);      // requests stay where they are written (one k-step / one step ahead)
@@ -211,6 +226,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
     constexpr int EK = decltype(EKIND)::value;
     constexpr bool last = EK == 2, first = EK == 0;
     PHASE_LANE();
+    if (PINN_PRIO) __builtin_amdgcn_s_setprio(PINN_PRIO == 1 ? 2 : 0);
     if (PINN_ABL & 16) {
 #pragma unroll
       for (int fb = 0; fb < 2; ++fb)
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
       for (int q = 0; q < 4; ++q) __syncthreads();
       return;
     }
-    float* const Sl = a.S + ((size_t)tileE * L + lE) * ((size_t)HP * COLS);
+    float* const Sl = a.S + spill_off(tileE, lE, L, a.sl0, a.sblk, (size_t)HP * COLS);
     const float* const bE = biasL + (size_t)lE * HP;
     float po[3][4];
 #pragma unroll
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
           const float d2 = -2.f * t * d1;
           av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
           sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
-          __builtin_amdgcn_sched_barrier(0);
+          E_SB();
         }
         const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + col;
         u32x4 pk[3];      // the quad's 24-bit spill: hi16 of streams 0-1, hi16 of streams 2-3, lo8 of all four
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(2 * HP, 1) void fwd_split_kernel(FwdArgs a) {
             if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Sl) + 2 * PLQ) + so);
           }
           if (last) asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));   // (no sinking behind the loop)
-          __builtin_amdgcn_sched_barrier(0);
+          E_SB();
         }
         __builtin_amdgcn_sched_barrier(0);        // 128 arch VGPRs: do not interleave the two quads' live ranges
       }
@@ -388,7 +404,7 @@ static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   const size_t lds = SplitLds<HP>::bytes(a.L);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_split_kernel<HP, TERMS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_split_kernel<HP, TERMS>), dim3(grid), dim3(2 * HP), lds, s, a);

@@ -319,7 +319,7 @@ static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   size_t lds = lds_bytes_t<HP>(a.L);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_bf16_wide_kernel<HP, NS, TERMS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_bf16_wide_kernel<HP, NS, TERMS>), dim3(grid), dim3(((HP / 32 + 1) / 2) * 64), lds, s, a);

@@ -191,7 +191,7 @@ static int launch_one(const FwdArgs& a, int grid, hipStream_t s) {
   size_t lds = fwd_wide_lds_bytes(HP);
   if (a.configure) {   // pinn_plan_create: raise the kernel's dynamic-LDS limit on the current device
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fwd_wide_kernel<HP, NS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, PINN_LDS_MAX);
     return e == hipSuccess ? 0 : -(int)e;
   }
   hipLaunchKernelGGL((fwd_wide_kernel<HP, NS>), dim3(grid), dim3(HP * 2), lds, s, a);

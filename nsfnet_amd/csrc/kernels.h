@@ -46,7 +46,14 @@ struct FwdArgs {
   int stagger;           // start offset unit (x 4096 cycles x (block*5 mod 8)); 0 = off
   int configure;         // 1: do not launch, only raise the kernel's dynamic-LDS limit (pinn_plan_create)
   int s24;               // wide bf16 residual kernels: S / Z-bar in the 24-bit three-plane spill format (bf16_util.h pack24)
+  // role-split sweeps (compact spill): block (tile, layer l) of S / Z-bar starts at ((size_t)tile * (L - sl0) + (l - sl0)) * sblk
+  // floats - only what the sweeps write is allocated: three 16-byte planes, no layer 0 (sl0 = 1)
+  int sl0; size_t sblk;
 };
+// float offset of the spill block of (tile, layer l); `sblk` == 0 selects the classic [tile][L][HP x columns] layout
+PINN_HD size_t spill_off(int tile, int l, int L, int sl0, size_t sblk, size_t classic) {
+  return sblk ? ((size_t)tile * (L - sl0) + (l > sl0 ? l - sl0 : 0)) * sblk : ((size_t)tile * L + l) * classic;
+}
 
 struct BwdArgs {
   const float* x; const float* y;
@@ -64,6 +71,7 @@ struct BwdArgs {
   float* sg;             // [grid][sg_total]
   int configure;         // see FwdArgs
   int s24;               // see FwdArgs
+  int sl0; size_t sblk;  // see FwdArgs
 };
 
 struct DwArgs {
@@ -76,6 +84,7 @@ struct DwArgs {
   int s0_skip;
   int s24;               // see FwdArgs (dw_bf16_wide)
   const float* x; const float* y; const float* prep; int n;
+  int sl0; size_t sblk;  // see FwdArgs
 };
 
 struct ReduceSrc { const float* slabs; int groups; const float* sg; int nwg; };

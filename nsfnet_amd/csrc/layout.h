@@ -25,6 +25,11 @@
 #define PINN_TILE_COLS 128
 #define PINN_MAX_HP 512      // <= 256: 128-column tiles (all precisions); 257..512: 64-column tiles (fp32)
 #define PINN_NLOSS 8   // loss partial slots per workgroup
+// Dynamic-LDS limit every kernel is configured with (hipFuncAttributeMaxDynamicSharedMemorySize): the device maximum,
+// NOT the configuring plan's own byte count - the limit is per kernel instantiation, and two live plans that share an
+// instantiation (same width, different depth) must not lower each other's limit.  pinn_plan_create rejects plans
+// whose kernels need more.
+#define PINN_LDS_MAX 163840
 
 // ---- prepared-parameter buffer (floats) -----------------------------------
 //   [w0x HP][w0y HP][b0 HP]

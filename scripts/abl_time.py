@@ -11,6 +11,7 @@ ap.add_argument("--what", default="fwd")
 ap.add_argument("--tag", default="")
 ap.add_argument("--prec", default="bf16x3")
 ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--zero", action="store_true", help="all parameters zero: every MFMA operand is zero (power / clock experiment)")
 a = ap.parse_args()
 from nsfnet_amd import engine as eng
 dev = torch.device("cuda:0")
@@ -18,7 +19,7 @@ L, H, Re = a.layers, 256, 2000.0
 x, y = bench.grid_block(a.grid, a.grid, 0, 1)
 xb, yb, ub, vb = bench.cavity_boundary()
 e = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, precision=a.prec)
-e.net.set_flat(bench.seeded_flat(L, H))
+e.net.set_flat(bench.seeded_flat(L, H) * (0.0 if a.zero else 1.0))
 e.set_collocation(x, y); e.set_boundary(xb, yb, ub, vb)
 f = e.plan_f
 c = 2.0 / x.size

@@ -19,6 +19,8 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE
-cp -f $ROOT/profiles/r02_pmc.json $OUT/pmc.json 2>/dev/null
-python3 $ROOT/scripts/pmc_summarize.py $OUT --json $OUT/pmc.json --precision $PREC > $OUT/summary.txt 2>&1
+cp -f $ROOT/profiles/r03_pmc.json $OUT/pmc.json 2>/dev/null
+# (the shape label follows the bench arguments: `--config N` in EXTRA selects that BASELINE shape)
+CFG=$(echo " $EXTRA" | sed -n 's/.*--config[ =]\([0-9]\).*/--config \1/p')
+python3 $ROOT/scripts/pmc_summarize.py $OUT --json $OUT/pmc.json --precision $PREC $CFG > $OUT/summary.txt 2>&1
 tail -40 $OUT/summary.txt

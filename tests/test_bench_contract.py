@@ -44,6 +44,7 @@ def test_bench_json_line():
     d = _one_json_line(out)
     _check_common(d, 1, 3, 1)
     assert d["config"]["workload"].startswith("custom")        # not a BASELINE shape: says so
+    assert d["config"]["backend"] == "none" and "alts" not in d
     assert d["roofline"]["traffic"] is None                     # PMC figures only for the shape they were measured on
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
@@ -79,6 +80,7 @@ def test_bench_self_launches_two_ranks():
     d = _one_json_line(out)
     _check_common(d, 2, 4, 2)
     assert d["config"]["global_points"] == 2 * 64 * 64 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["backend"] == "gloo"      # a rehearsal can never be mistaken for the RCCL run ("rccl")
     assert d["cpu_baseline"] is None
 
 
@@ -113,3 +115,57 @@ def test_self_launcher_starts_children_and_forwards_one_line(tmp_path):
     bad = subprocess.run([sys.executable, "-c", driver, "--gpus", "2", "--fail"], capture_output=True, text=True,
                          env=env, timeout=300)
     assert bad.returncode != 0
+
+
+def test_strong_scaling_blocks_tile_the_fixed_total():
+    """--scaling strong: config 3's net on 2.88 M points IN TOTAL, equal row blocks per rank."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    nx, ny = bench.CONFIGS[3]["grid"]
+    assert bench.local_rows(nx, "weak", 4) == nx
+    ref_x = (np.arange(8 * nx) + 0.5) / (8 * nx)
+    for world in (1, 2, 4, 8):
+        rows = bench.local_rows(nx, "strong", world)
+        assert rows * world * ny == 2_880_000
+        xs = []
+        for r in range(world):
+            x, y = bench.grid_block(rows, ny, r, world)
+            assert x.size == rows * ny == 2_880_000 // world
+            xs.append(np.unique(x))
+        assert np.allclose(np.concatenate(xs), ref_x.astype(np.float32))        # disjoint, ordered, complete
+    with pytest.raises(SystemExit):
+        bench.local_rows(nx, "strong", 7)
+
+
+def test_strong_scaling_two_gloo_ranks(tmp_path):
+    """The N = 2 case as the driver would start it (torch.distributed.run, 127.0.0.1), on CPU over gloo: every rank
+    derives its block from RANK / WORLD_SIZE alone, the blocks have 2.88 M / N points and add up to the fixed total."""
+    script = tmp_path / "strong_ranks.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        import bench
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        sys.argv = ["bench.py", "--scaling", "strong", "--gpus", str(w)]
+        args = bench.parse_args()
+        rows = bench.local_rows(args.nx, args.scaling, w)
+        x, y = bench.grid_block(rows, args.ny, r, w)
+        t = torch.tensor([float(x.size), float(x.min()), float(x.max())], dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(w)]
+        dist.all_gather(out, t)
+        if r == 0:
+            n = sum(int(o[0]) for o in out)
+            assert n == 2_880_000 and all(int(o[0]) == n // w for o in out), out
+            assert out[0][2] < out[1][1]                      # rank 0's rows end before rank 1's start
+            print("STRONG_OK", n, args.alt_list)
+        dist.destroy_process_group()
+    """ % ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29713", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "STRONG_OK 2880000 []" in out.stdout            # (no alt modes in the strong table)

@@ -65,3 +65,34 @@ def test_config3_shape_run_matches_dns(monkeypatch, tmp_path):
     t_net, t_dns = ft.topology(X, Y, u, v), ft.topology(X, Y, U, V)
     assert abs(t_net["primary"]["x"] - t_dns["primary"]["x"]) < 0.03 and abs(t_net["primary"]["y"] - t_dns["primary"]["y"]) < 0.03, (
         t_net["primary"], t_dns["primary"])
+
+
+def test_config4_dns_file_evaluate_and_test_on_the_385_grid(monkeypatch, tmp_path, capsys):
+    """BASELINE config 4 names cavity_Re4000_384_Uniform.mat: a 385 x 385 grid, the case that breaks the reference's
+    hard-coded 257 x 257 reshape in test() (ev-NSFnet/pinn_solver.py:723-726; NSFnet/pinn_solver.py:348-350).  evaluate()
+    and test() of the ev drop-in class on that file, config 4's net shape (6x256 + 4x40): the grid shape comes from the
+    data and the saved .mat holds 385 x 385 fields.  (Seeded weights - no Re = 4000 run of this engine exists yet, so the
+    errors themselves are not a statement; the trained-weights gates are the tests above.)"""
+    import scipy.io
+    monkeypatch.setenv("NSFNET_PRECISION", "bf16x3")
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    torch.manual_seed(4000)
+    from nsfnet_amd import ev_pinn_solver as es, cavity_data as cavity
+    P = es.PysicsInformedNeuralNetwork(Re=4000, layers=6, layers_1=4, hidden_size=256, hidden_size_1=40, N_f=1000,
+                                       alpha_evm=0.03)
+    star = cavity.EvDataLoader(N_f=1000).loading_evaluate_data(os.path.join(HERE, "golden", "dns", "cavity_Re4000_384_Uniform.mat"))
+    assert star[0].shape[0] == 385 * 385
+    eu, ev, ep = P.evaluate(*star)
+    assert np.isfinite([eu, ev, ep]).all() and "Error u" in capsys.readouterr().out
+    out_dir = str(tmp_path / "res")
+    tu, tv, tp = P.test(*star, loop=0, save_dir=out_dir)
+    assert abs(tu - eu) < 1e-6 and abs(tv - ev) < 1e-6
+    m = scipy.io.loadmat(os.path.join(out_dir, "cavity_result_loop_0.mat"))
+    for key in ("U_pred", "V_pred", "P_pred", "E_pred"):
+        assert m[key].shape == (385, 385), (key, m[key].shape)
+    # the saved field is the network's prediction on the file's own grid, row for row
+    u_pred = P.predict(None, (star[0], star[1]))[0]
+    u_pred = u_pred.detach().cpu().numpy() if hasattr(u_pred, "detach") else np.asarray(u_pred)
+    np.testing.assert_allclose(m["U_pred"].reshape(-1), u_pred.reshape(-1), rtol=0, atol=1e-6)

@@ -55,3 +55,28 @@ def test_pack24_round_trip_is_round_to_24_bits():
         assert hi0 == ((r[0] >> 16) | (r[1] & 0xffff0000)) and hi1 == ((r[2] >> 16) | (r[3] & 0xffff0000))
         assert lo == sum(((r[i] >> 8) & 0xff) << (8 * i) for i in range(4))
     assert worst <= 2.0 ** -16
+
+
+def test_pack24_keeps_the_nans_and_infinities_arithmetic_produces():
+    """A diverged activation must still poison the reverse sweep after the spill.  Pinned: +-infinity, the hardware's
+    quiet NaNs and every quiet NaN with a payload below 0x7fff80 keep their class; the largest finite value rounds up to
+    infinity.  Documented in bf16_util.h and NOT guarded (three VALU per value in the hottest loop): an all-ones payload
+    carries into the exponent and reads back as zero - no instruction of the sweeps produces such a NaN."""
+    hi_a, hi_b, lo_a, lo_b, u0, u1, u2, u3 = _selectors()
+    cases = [0x7fc00000, 0xffc00000, 0x7fc00001, 0xffd12345, 0x7fff7f7f, 0x7f800000, 0xff800000, 0x7f7fffff]
+    for k in range(0, len(cases), 4):
+        r = [(u + 0x80) & 0xffffffff for u in cases[k:k + 4]]
+        hi0, hi1 = v_perm_b32(r[1], r[0], hi_a), v_perm_b32(r[3], r[2], hi_b)
+        lo = v_perm_b32(r[1], r[0], lo_a) | v_perm_b32(r[3], r[2], lo_b)
+        y = np.array([v_perm_b32(hi0, lo, u0), v_perm_b32(hi0, lo, u1), v_perm_b32(hi1, lo, u2), v_perm_b32(hi1, lo, u3)],
+                     dtype=np.uint32).view(np.float32)
+        for u, b in zip(cases[k:k + 4], y):
+            a = np.array([u], dtype=np.uint32).view(np.float32)[0]
+            if np.isnan(a):
+                assert np.isnan(b), hex(u)
+            elif np.isinf(a):
+                assert b == a, hex(u)
+            else:
+                assert np.isinf(b) and np.sign(b) == np.sign(a), hex(u)      # the largest finite value rounds up to infinity
+    # the documented hole: the carry of an all-ones payload
+    assert ((0x7fffffff + 0x80) & 0xffffff00) == 0x80000000
