@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnsfnet_pinn.so")
 SOURCES = ["fwd.hip", "bwd.hip", "dw.hip", "fwd_bf16.hip", "bwd_bf16.hip", "dw_bf16.hip", "fwd_wide.hip", "bwd_wide.hip", "dw_wide.hip",
-           "fwd_bf16_wide.hip", "bwd_bf16_wide.hip", "dw_bf16_wide.hip", "fwd_bf16_pipe.hip", "bwd_bf16_pipe.hip", "fwd_bf16_split.hip", "bwd_bf16_split.hip", "misc.hip", "capi.hip"]
+           "fwd_bf16_wide.hip", "bwd_bf16_wide.hip", "dw_bf16_wide.hip", "fwd_bf16_pipe.hip", "bwd_bf16_pipe.hip", "fwd_bf16_split.hip", "bwd_bf16_split.hip", "fwd_bf16_wsplit.hip", "bwd_bf16_wsplit.hip", "misc.hip", "capi.hip"]
 HEADERS = ["kernels.h", "layout.h", "bf16_util.h", "reduce_util.h", "point_stage.h", os.path.join("..", "..", "include", "nsfnet_pinn.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras.  The pipelined kernels place their epilogue VALU in MFMA shadows: packed-f32 VALU (v_pk_*_f32, what
@@ -23,7 +23,8 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
 # -pragma-unroll-threshold: a slot body (64 steps x (6 MFMAs + an epilogue slice)) must unroll completely - register
 # arrays are indexed by the step - and is larger than the default cap on `#pragma unroll`.
 _PIPE = ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"]
-EXTRA_FLAGS = {"fwd_bf16_pipe.hip": _PIPE, "bwd_bf16_pipe.hip": _PIPE, "fwd_bf16_split.hip": _PIPE, "bwd_bf16_split.hip": _PIPE}
+EXTRA_FLAGS = {"fwd_bf16_pipe.hip": _PIPE, "bwd_bf16_pipe.hip": _PIPE, "fwd_bf16_split.hip": _PIPE, "bwd_bf16_split.hip": _PIPE,
+               "fwd_bf16_wsplit.hip": _PIPE, "bwd_bf16_wsplit.hip": _PIPE}
 
 
 def _hipcc():

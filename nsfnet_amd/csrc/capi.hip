@@ -54,6 +54,7 @@ struct pinn_plan_s {
   int stagger;           // $PINN_STAGGER, read once at plan creation
   int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
   int pipe_b;            // schedule of the reverse sweep; for 1 / 2 grid_b is the pair grid
+  int wsplit;            // wide net (hidden > 256): role-split sweeps at 64-column tiles (fwd / bwd_bf16_wsplit.hip) instead of the 8-wave ones
   // workspace offsets in bytes
   size_t off_partials, off_oadj, off_sg, off_slabs, off_S, off_Zb, bytes_fwd, bytes_all;
 };
@@ -80,6 +81,7 @@ static int env_int(const char* name, int dflt) {
 static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s, bool pipe = false) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (pipe && plan->wsplit) return launch_fwd_wsplit(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s);
   if (pipe) return plan->pipe_f == 2 ? launch_fwd_split(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s)
                                      : launch_fwd_pipe(n.HP, terms_of(n.prec_fwd), a, plan->grid_fp, s);
   if (n.prec_fwd)
@@ -90,6 +92,7 @@ static int dispatch_fwd(const pinn_plan_s* plan, const FwdArgs& a, hipStream_t s
 static int dispatch_bwd(const pinn_plan_s* plan, const BwdArgs& a, hipStream_t s) {
   const pinn_net_s& n = plan->net;
   const int cols = n.wide ? 64 : 128, NS = plan->streams;
+  if (plan->wsplit) return launch_bwd_wsplit(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (plan->pipe_b == 2) return launch_bwd_split(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (plan->pipe_b) return launch_bwd_pipe(n.HP, terms_of(n.prec_bwd), a, plan->grid_b, s);
   if (n.prec_bwd)
@@ -196,6 +199,11 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   // wide nets (hidden > 256), all three kernels in a bf16 mode, residual mode: the same 24-bit spill format
   p->s24w = HP > 256 && streams == 4 && net->prec_fwd && net->prec_bwd && net->prec_dw;
   if (!p->s0_skip) { if (p->pipe_f == 2) p->pipe_f = 1; if (p->pipe_b == 2) p->pipe_b = 1; }
+  // wide nets in the 24-bit format: the role-split sweeps at 64-column tiles where their LDS fits (hidden <= 448: the last
+  // K region must fit twice in the 512-element image rows); $PINN_WSPLIT=0 keeps the 8-wave kernels.  Forward-only
+  // calls (save = 0) always take the 8-wave kernel.
+  p->wsplit = p->s24w && L >= 2 && env_int("PINN_WSPLIT", 1) != 0 && fwd_wsplit_lds_bytes(HP) <= PINN_LDS_MAX &&
+              bwd_wsplit_lds_bytes(HP, L) <= PINN_LDS_MAX;
   p->grid_fp = cus < (p->ntiles + 1) / 2 ? cus : (p->ntiles + 1) / 2;
   p->stagger = env_int("PINN_STAGGER", 0);
   if (env_int("PINN_VERBOSE", 0))
@@ -203,7 +211,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
             (long)n_points, streams, HP, L, net->prec_fwd, net->prec_bwd, net->prec_dw, (int)wide, p->pipe_f, p->pipe_b);
   p->grid_b = cus * bpc(lds_b);
   if (p->grid_b > p->ntiles) p->grid_b = p->ntiles;
-  if (p->pipe_b) p->grid_b = p->grid_fp;
+  if (p->pipe_b || p->wsplit) p->grid_b = p->grid_fp;
   if (L > 1) {
     int g = cus * bpc(lds_d) / (L - 1);
     if (g < 1) g = 1;
@@ -239,7 +247,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
     BwdArgs ba; memset(&ba, 0, sizeof(ba)); ba.L = L; ba.configure = 1;
     DwArgs da;  memset(&da, 0, sizeof(da)); da.L = L; da.groups = p->groups; da.configure = 1; da.s0_skip = p->s0_skip; da.s24 = p->s24w;
     int rc = dispatch_fwd(p, fa, nullptr);
-    if (!rc && p->pipe_f) rc = dispatch_fwd(p, fa, nullptr, true);
+    if (!rc && (p->pipe_f || p->wsplit)) rc = dispatch_fwd(p, fa, nullptr, true);
     if (!rc) rc = dispatch_bwd(p, ba, nullptr);
     if (!rc) rc = dispatch_dw(p, da, nullptr);
     if (rc) { delete p; return hipfail(rc, "pinn_plan_create(kernel attributes)"); }
@@ -253,6 +261,8 @@ const char* pinn_plan_kernel(pinn_plan_t plan, int which) {
   if (!plan || which < 0 || which > 2) return nullptr;
   const pinn_net_s& n = plan->net;
   const bool wbf = n.HP > 256;
+  if (which == 0 && plan->wsplit) return "fwd_wsplit_kernel";
+  if (which == 1 && plan->wsplit) return "bwd_wsplit_kernel";
   if (which == 0) return plan->pipe_f == 2 ? "fwd_split_kernel" : plan->pipe_f ? "fwd_pipe_kernel" : n.prec_fwd ? (wbf ? "fwd_bf16_wide_kernel" : "fwd_bf16_kernel")
                                       : n.wide ? "fwd_wide_kernel" : "fwd_kernel";
   if (which == 1) return plan->pipe_b == 2 ? "bwd_split_kernel" : plan->pipe_b ? "bwd_pipe_kernel" : n.prec_bwd ? (wbf ? "bwd_bf16_wide_kernel" : "bwd_bf16_kernel")
@@ -284,7 +294,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? plan->stagger : 0;
   a.sl0 = plan->sl0; a.sblk = plan->sblk;
-  const bool pipe = plan->pipe_f && save;
+  const bool pipe = (plan->pipe_f || plan->wsplit) && save;
   int rc = dispatch_fwd(plan, a, (hipStream_t)stream, pipe);
   if (rc) return hipfail(rc, "pinn_residual_forward");
   if (loss_sums) {

@@ -136,6 +136,11 @@ int launch_bwd_split(int HP, int terms, const BwdArgs& a, int grid, hipStream_t 
 size_t bwd_split_lds_bytes(int HP, int L);
 int launch_bwd_pipe(int HP, int terms, const BwdArgs& a, int grid, hipStream_t s);
 size_t bwd_pipe_lds_bytes(int HP, int L);
+// wide nets (256 < HP <= 448), residual mode, 24-bit spill: the role-split schedule at 64-column tiles (fwd_bf16_wsplit.hip)
+int launch_fwd_wsplit(int HP, int terms, const FwdArgs& a, int grid, hipStream_t s);
+size_t fwd_wsplit_lds_bytes(int HP);
+int launch_bwd_wsplit(int HP, int terms, const BwdArgs& a, int grid, hipStream_t s);
+size_t bwd_wsplit_lds_bytes(int HP, int L);
 int launch_reduce(const ReduceArgs& a, hipStream_t s);
 int launch_loss_sums(const float* partials, int nparts, float* out, hipStream_t s);
 int launch_adam_dev(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,

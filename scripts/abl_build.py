@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nsfnet_amd import build as B
 
-VARIANT_SOURCES = {"dw_bf16.hip"}      # recompiled per variant beside the pipelined / role-split sweeps
+VARIANT_SOURCES = {"dw_bf16.hip", "dw_bf16_wide.hip"}      # recompiled per variant beside the pipelined / role-split sweeps
 
 
 def main():

@@ -6,17 +6,19 @@ import numpy as np, torch
 import bench
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--grid", type=int, default=600)
+ap.add_argument("--grid", default="600", help="G (= GxG) or AxB")
 ap.add_argument("--what", default="fwd")
 ap.add_argument("--tag", default="")
 ap.add_argument("--prec", default="bf16x3")
 ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--zero", action="store_true", help="all parameters zero: every MFMA operand is zero (power / clock experiment)")
 a = ap.parse_args()
 from nsfnet_amd import engine as eng
 dev = torch.device("cuda:0")
-L, H, Re = a.layers, 256, 2000.0
-x, y = bench.grid_block(a.grid, a.grid, 0, 1)
+L, H, Re = a.layers, a.hidden, 2000.0
+g = [int(v) for v in str(a.grid).lower().split("x")]
+x, y = bench.grid_block(g[0], g[-1], 0, 1)
 xb, yb, ub, vb = bench.cavity_boundary()
 e = eng.PinnEngine(dev, L, H, Re, alpha_b=10.0, alpha_e=1.0, precision=a.prec)
 e.net.set_flat(bench.seeded_flat(L, H) * (0.0 if a.zero else 1.0))
