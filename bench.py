@@ -408,6 +408,7 @@ def main():
                                # what moved the per-step all-reduce: "rccl" (torch backend "nccl" on ROCm) is the product
                                # path; "gloo" only ever appears in single-GPU rehearsals of the rank logic
                                backend={"nccl": "rccl"}.get(backend, backend),
+                               peak_device_mem_gb=round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                                csrc_hash=csrc_hash()),
                    roofline=roofline, sustained=sustained)
         if args.alt_list and world == 1:

@@ -343,6 +343,11 @@ class PinnEngine:
         self.n_f_global = self.n_b_global = self.n_s_global = 0
         self._n_p_local, self._n_p_valid, self._sup_stale = 0, None, False
         self.eq4_weight = 0.1
+        # 'MSE' (every script of the reference) or 'L2': 2-norms of the residual / boundary-misfit vectors
+        # (NSFnet/pinn_solver.py:202-204, 214-217; plain NSFnet, one GPU).  The same kernels run: only the adjoint
+        # coefficients change, from 2 alpha / N to alpha / ||r_k||, and the norms have to be known first - one
+        # host read of the forward sums per evaluation (no hipGraph in this mode).
+        self.loss_mode = "MSE"
 
     # ---- views into the exchange buffer ----
     @property
@@ -435,9 +440,18 @@ class PinnEngine:
             side = self._side_stream(main)
             side.wait_stream(main)
             torch.cuda.set_stream(side)
+        l2 = self.loss_mode == "L2"
+        if l2 and (self.net_e is not None or self.world_size > 1 or sup_on or isinstance(f, ChunkedResidual)):
+            raise NotImplementedError("loss_mode 'L2' exists for the plain NSFnet flavour on one GPU (NSFnet/pinn_solver.py:202-217)")
         try:
             cb = 2.0 * self.alpha_b / self.n_b_global
-            b.forward(coef=(cb, cb, 0.0), save=True, sums_out=sums[S_BC:S_BC + NLOSS])
+            if l2:      # norms first (2052 boundary points: a forward-only pass), then the adjoints alpha_b (u - u_b) / ||u - u_b||
+                b.forward(coef=(0.0, 0.0, 0.0), save=False, sums_out=sums[S_BC:S_BC + NLOSS])
+                nb = torch.sqrt(sums[S_BC:S_BC + 2]).cpu().numpy().astype(np.float64)
+                b.forward(coef=(self.alpha_b / max(nb[0], 1e-30), self.alpha_b / max(nb[1], 1e-30), 0.0), save=True,
+                          sums_out=sums[S_BC:S_BC + NLOSS])
+            else:
+                b.forward(coef=(cb, cb, 0.0), save=True, sums_out=sums[S_BC:S_BC + NLOSS])
             b.backward()
             if s is not None:
                 # per-output means: u,v over all supervised points, p over its finite targets (ev:399-411)
@@ -471,6 +485,9 @@ class PinnEngine:
         else:
             f.forward(self.Re, e=e, vis_t0=self.vis_t0, alpha_evm=self.alpha_evm, scale=self.scale, save=True,
                       sums_out=sums[S_EQ:S_EQ + NLOSS])
+            if l2:      # d ||eq_k|| / d theta = sum eq_k d eq_k / ||eq_k||: the reverse sweep's seeds with alpha_e / ||eq_k||
+                ne = torch.sqrt(sums[S_EQ:S_EQ + 3]).cpu().numpy().astype(np.float64)
+                coef_eq = tuple(self.alpha_e / max(v, 1e-30) for v in ne) + (0.0,)
             f.backward(self.Re, coef_eq, e=e, scale=self.scale, want_ebar=self.e_trainable)
             if side is not None:
                 main.wait_stream(side)
@@ -504,6 +521,12 @@ class PinnEngine:
     def loss_terms(self):
         """Device tensors (no sync): dict of loss_eq1..4, loss_e, loss_b, loss_s, loss."""
         s = self.sums
+        if self.loss_mode == "L2":      # NSFnet/pinn_solver.py:202-204, 214-217
+            eq = torch.sqrt(s[S_EQ:S_EQ + 4])
+            loss_e = eq[0] + eq[1] + eq[2]
+            loss_b = torch.sqrt(s[S_BC]) + torch.sqrt(s[S_BC + 1])
+            return dict(loss_eq1=eq[0], loss_eq2=eq[1], loss_eq3=eq[2], loss_eq4=eq[3], loss_e=loss_e, loss_b=loss_b,
+                        loss_s=torch.zeros((), device=self.device), loss=self.alpha_b * loss_b + self.alpha_e * loss_e)
         eq = s[S_EQ:S_EQ + 4] / self.n_f_global
         loss_e = eq[0] + eq[1] + eq[2] + (self.eq4_weight * eq[3] if self.net_e is not None else 0.0)
         loss_b = (s[S_BC] + s[S_BC + 1]) / self.n_b_global
@@ -526,7 +549,7 @@ class PinnEngine:
         once per (lr, schedule state) in a hipGraph and replayed.  Opt-in: measured on MI355X the eager
         launch sequence (~14 launches, all asynchronous) already keeps the GPU busy down to the 4x50 /
         10 k-point step (0.12 ms), and replay is 0-6 % slower; it pays only when the host is contended."""
-        if not self._graphs_enabled():
+        if not self._graphs_enabled() or self.loss_mode != "MSE":
             self.loss_and_grad()
             self.adam_step(lr)
             return

@@ -139,7 +139,13 @@ class PysicsInformedNeuralNetwork:
 
     # ---------------------------------------------------------------- loss / step
     def _publish_terms(self):
-        t = self.engine.loss_terms()
+        mode = getattr(self, "_loss_mode_published", "MSE")
+        self.engine.loss_mode = mode
+        try:
+            t = self.engine.loss_terms()
+        finally:
+            self.engine.loss_mode = "MSE"
+        self._loss_mode_published = "MSE"
         f = self.engine.plan_f
         self.loss_eq1, self.loss_eq2, self.loss_eq3 = t["loss_eq1"], t["loss_eq2"], t["loss_eq3"]
         self.loss_e, self.loss_b, self.loss = t["loss_e"], t["loss_b"], t["loss"]
@@ -152,10 +158,17 @@ class PysicsInformedNeuralNetwork:
         """Loss of the current parameters AND its parameter gradient (the HIP pipeline fuses
         what the reference splits into this call and ``loss.backward()``, solver :197-226,252).
         Returns (loss, [loss_e, loss_b]) as 0-dim device tensors."""
-        if loss_mode != 'MSE':
-            raise NotImplementedError("only the MSE loss is implemented (the reference never selects 'L2')")
+        if loss_mode not in ('MSE', 'L2'):
+            raise ValueError("loss_mode must be 'MSE' or 'L2'")
         assert self.x_f is not None and self.y_f is not None
-        self.engine.loss_and_grad()
+        # 'L2' (solver :202-204, :214-217; no script of the reference selects it): 2-norms of the residual and
+        # boundary-misfit vectors instead of mean squares - same kernels, other adjoint coefficients (engine.loss_mode)
+        self.engine.loss_mode = loss_mode
+        try:
+            self.engine.loss_and_grad()
+        finally:
+            self.engine.loss_mode = 'MSE'
+            self._loss_mode_published = loss_mode
         self._publish_terms()
         return self.loss, [self.loss_e, self.loss_b]
 

@@ -109,9 +109,10 @@ class NSFnetOracle:
     (pinn_solver.py:228-238).
     """
 
-    def __init__(self, net, Re, alpha_b=1.0, alpha_e=1.0, lr=1e-3):
+    def __init__(self, net, Re, alpha_b=1.0, alpha_e=1.0, lr=1e-3, loss_mode="MSE"):
         self.net, self.Re = net, Re
         self.alpha_b, self.alpha_e = alpha_b, alpha_e
+        self.loss_mode = loss_mode      # 'MSE' | 'L2' (NSFnet/pinn_solver.py:202-217; no script selects 'L2')
         self.opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=0)
 
     def set_data(self, x_f, y_f, x_b, y_b, u_b, v_b):
@@ -121,10 +122,16 @@ class NSFnetOracle:
         self.x_b, self.y_b, self.u_b, self.v_b = t(x_b), t(y_b), t(u_b), t(v_b)
 
     def loss(self):
-        self.loss_b = bc_loss(self.net, self.x_b, self.y_b, self.u_b, self.v_b)
         self.eq1, self.eq2, self.eq3, self.fields = nsfnet_residuals(
             self.net, self.x_f, self.y_f, self.Re)
-        self.loss_eq = [torch.mean(torch.square(e.reshape(-1))) for e in (self.eq1, self.eq2, self.eq3)]
+        if self.loss_mode == "L2":      # 2-norms instead of mean squares (NSFnet/pinn_solver.py:202-204, 214-217)
+            out = self.net(torch.cat((self.x_b, self.y_b), dim=1))
+            self.loss_b = (torch.norm(self.u_b.reshape(-1) - out[:, 0], p=2) +
+                           torch.norm(self.v_b.reshape(-1) - out[:, 1], p=2))
+            self.loss_eq = [torch.norm(e.reshape(-1), p=2) for e in (self.eq1, self.eq2, self.eq3)]
+        else:
+            self.loss_b = bc_loss(self.net, self.x_b, self.y_b, self.u_b, self.v_b)
+            self.loss_eq = [torch.mean(torch.square(e.reshape(-1))) for e in (self.eq1, self.eq2, self.eq3)]
         self.loss_e = self.loss_eq[0] + self.loss_eq[1] + self.loss_eq[2]
         self.total = self.alpha_b * self.loss_b + self.alpha_e * self.loss_e
         return self.total

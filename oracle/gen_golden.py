@@ -89,6 +89,36 @@ def gen_nsfnet(mods, name, L, H, N, Re, seed, steps, alpha_b=10.0, alpha_e=1.0, 
     print(name, "loss0", losses[0])
 
 
+def gen_nsfnet_l2(mods, name, L, H, N, Re, seed, steps, alpha_b=10.0, alpha_e=1.0, lr=1e-3):
+    """loss_mode='L2' of the plain solver (NSFnet/pinn_solver.py:202-204, 214-217): 2-norms instead of mean squares.
+    No script of the reference selects it; the branch is driven here directly."""
+    ps = mods["pinn_solver"]
+    torch.manual_seed(seed)
+    P = ps.PysicsInformedNeuralNetwork(Re=Re, layers=L, hidden_size=H, N_f=N, bc_weight=alpha_b, eq_weight=alpha_e,
+                                       learning_rate=lr, num_ins=2, num_outs=3)
+    bc = mods["cavity_data"].DataLoader(N_f=N).loading_boundary_data()
+    bc = tuple(a[::8] for a in bc)
+    x, y = _points(N, seed + 1)
+    P.set_boundary_data(X=bc)
+    P.set_eq_training_data(X=(x, y))
+    rec = dict(L=L, H=H, N=N, Re=Re, seed=seed, alpha_b=alpha_b, alpha_e=alpha_e, lr=lr, x=x, y=y, w0=_flat(P.net),
+               x_b=bc[0], y_b=bc[1], u_b=bc[2], v_b=bc[3])
+    losses, params = [], []
+    for k in range(steps):
+        loss, (loss_e, loss_b) = P.fwd_computing_loss_2d(loss_mode='L2')
+        loss.backward()
+        if k == 0:
+            rec["grad0"] = _flat(P.net, grad=True)
+        losses.append([float(loss), float(loss_b), float(loss_e)])
+        P.opt.step()
+        P.opt.zero_grad()
+        params.append(_flat(P.net))
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    rec["params_after"] = np.stack(params)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, "loss0", losses[0])
+
+
 def _make_ev(mods, L, H, L1, H1, Re, alpha_evm, alpha_b, alpha_e, lr, seed, coord_scale=1.0):
     """ev ctor hard-requires a GPU (ev-NSFnet/pinn_solver.py:62-63); build the
     object by hand with the attributes the ctor would set."""
@@ -299,12 +329,19 @@ def gen_data_prep(ns, ev):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = sys.argv[1] if len(sys.argv) > 1 else None      # `gen_golden.py l2`: only the fixture added in round 3
     with tempfile.TemporaryDirectory() as tmp:
         os.chdir(tmp)
         ns = _import_flavour("NSFnet")
+        if only == "l2":
+            gen_nsfnet_l2(ns, "nsfnet_l2_3x24_re400", 3, 24, 200, 400, 5, 3)
+            os.chdir("/tmp")
+            return
         gen_nsfnet(ns, "nsfnet_4x50_re100", 4, 50, 2048, 100, 0, 3)
         gen_nsfnet(ns, "nsfnet_2x16_re1000", 2, 16, 300, 1000, 3, 5)
         gen_nsfnet(ns, "nsfnet_6x256_re2000_n256", 6, 256, 256, 2000, 1234, 1, store_weights=False, stride=16)
+        if only in (None, "l2"):
+            gen_nsfnet_l2(ns, "nsfnet_l2_3x24_re400", 3, 24, 200, 400, 5, 3)
         ev = _import_flavour("ev-NSFnet")
         gen_ev(ev, "ev_4x50_4x40_re4000", 4, 50, 4, 40, 1024, 4000, 0.05, 11, 4)
         gen_ev(ev, "ev_2x16_sdf_scaled", 2, 16, 2, 12, 256, 3000, 0.03, 21, 4, sdf=True, coord_scale=2.0)

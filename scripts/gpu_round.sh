@@ -18,6 +18,14 @@ for step in "$@"; do
            rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_stats -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --alt-precision "" --sustain-seconds 0 > $ROOT/gpurun_out/${TAG}_stats.log 2>&1
            cp $(ls $ROOT/gpurun_out/${TAG}_stats/*/*kernel_stats.csv | head -1) $ROOT/gpurun_out/${TAG}_kernel_stats.csv; head -8 $ROOT/gpurun_out/${TAG}_kernel_stats.csv ;;
     pmc)   bash scripts/pmc_profile.sh bf16x3 $TAG ;;
+    pmc5)  cp -f gpurun_out/pmc_$TAG/pmc.json profiles/r03_pmc.json 2>/dev/null || true      # (config 5's entries join the same record)
+           bash scripts/pmc_profile.sh bf16x3 ${TAG}c5 --config 5 ;;
+    configs) for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/${TAG}_bench_config$c.json 2> gpurun_out/${TAG}_bench_config$c.err; python -c "
+import json,sys; d=json.load(open('gpurun_out/${TAG}_bench_config$c.json')); print('config $c', round(d['ms_per_step'],3), 'ms', d['roofline']['kernel_ms'], round(d['roofline']['frac'],4))"; done ;;
+    strong) python bench.py --scaling strong --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/${TAG}_bench_strong1.json 2> gpurun_out/${TAG}_bench_strong1.err; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_strong1.json')); print('strong N=1', d['config']['global_points'], round(d['ms_per_step'],3), 'ms', d['value'])" ;;
+    big)   python bench.py --grid 2000 --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --alt-precision "" > gpurun_out/${TAG}_bench_grid2000.json 2> gpurun_out/${TAG}_bench_grid2000.err; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_grid2000.json')); print('4 M points', round(d['ms_per_step'],2), 'ms', d['value'])"; grep -i "workspace\|GiB\|memory" gpurun_out/${TAG}_bench_grid2000.err | tail -3 ;;
     clock) cd /tmp && export TMPDIR=/tmp
            for z in "" "--zero"; do
              rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $ROOT/gpurun_out/${TAG}_clock$z -- python3 $ROOT/scripts/abl_time.py --what fwd,bwd,dw --tag "seeded$z" $z >> $ROOT/gpurun_out/${TAG}_clock.txt 2>&1

@@ -207,3 +207,19 @@ def test_adam_restatement(golden_dir):
     p, m, v = fr.adam_step(g["w0"].astype(np.float64), g["grad0"].astype(np.float64), 0.0, 0.0, 1, float(g["lr"]))
     assert _rel(p, g["params_after"][0]) < 1e-6
 
+
+
+def test_autograd_restatement_l2_loss_mode_vs_reference(golden_dir):
+    """loss_mode='L2' (NSFnet/pinn_solver.py:202-204, 214-217: 2-norms of the boundary misfit and the residuals instead of
+    mean squares) - fixture generated by the reference's own branch (oracle/gen_golden.py gen_nsfnet_l2)."""
+    g = _load(golden_dir, "nsfnet_l2_3x24_re400")
+    L, H, Re = int(g["L"]), int(g["H"]), float(g["Re"])
+    net = _net_from_flat(g["w0"], 3, L, H)
+    o = ar.NSFnetOracle(net, Re, alpha_b=float(g["alpha_b"]), alpha_e=float(g["alpha_e"]), lr=float(g["lr"]), loss_mode="L2")
+    o.set_data(g["x"], g["y"], g["x_b"], g["y_b"], g["u_b"], g["v_b"])
+    for k in range(g["losses"].shape[0]):
+        total = o.step()
+        np.testing.assert_allclose([total, float(o.loss_b.detach()), float(o.loss_e.detach())], g["losses"][k], rtol=2e-6)
+        if k == 0:
+            assert _rel(o.grads.numpy(), g["grad0"]) < 1e-5
+        assert _rel(ar.flat_params(net).numpy(), g["params_after"][k]) < 1e-5

@@ -223,3 +223,30 @@ def test_bf16x3_solver_loss_within_1e4_of_reference(golden_dir, name, tmp_path, 
         mine = [loss.item(), loss_b.item(), P.loss_eq1.item(), P.loss_eq2.item(), P.loss_eq3.item()]
         np.testing.assert_allclose(mine, g["losses"][k], rtol=1e-4)
         P.engine.adam_step(P.opt.param_groups[0]["lr"])
+
+
+def test_nsfnet_solver_l2_loss_mode_vs_reference(golden_dir, tmp_path, monkeypatch):
+    """fwd_computing_loss_2d(loss_mode='L2') of the drop-in class (NSFnet/pinn_solver.py:202-204, 214-217) against the
+    reference's own branch: loss, its two parts, the gradient and three Adam steps.  Same HIP kernels as the MSE mode,
+    adjoint coefficients alpha / ||r_k|| from one host read of the forward sums."""
+    from nsfnet_amd import pinn_solver as ps
+    monkeypatch.chdir(tmp_path)
+    g = _load(golden_dir, "nsfnet_l2_3x24_re400")
+    P = ps.PysicsInformedNeuralNetwork(Re=float(g["Re"]), layers=int(g["L"]), hidden_size=int(g["H"]),
+                                       N_f=int(g["N"]), bc_weight=float(g["alpha_b"]), eq_weight=float(g["alpha_e"]),
+                                       learning_rate=float(g["lr"]), num_ins=2, num_outs=3)
+    P.net.dev_net.set_flat(torch.tensor(g["w0"]))
+    P.set_boundary_data(X=(g["x_b"], g["y_b"], g["u_b"], g["v_b"]))
+    P.set_eq_training_data(X=(g["x"], g["y"]))
+    P.save_every = 0
+    w0 = g["w0"].astype(np.float64)
+    for k in range(g["losses"].shape[0]):
+        loss, (loss_e, loss_b) = P.fwd_computing_loss_2d(loss_mode='L2')
+        np.testing.assert_allclose([loss.item(), loss_b.item(), loss_e.item()], g["losses"][k], rtol=2e-5)
+        if k == 0:
+            assert _rel_l2(_np(P.engine.grads), g["grad0"]) < 1e-4
+        P.engine.adam_step(P.opt.param_groups[0]["lr"])
+        upd = _np(P.engine.net.params).astype(np.float64) - w0
+        assert _rel_l2(upd, g["params_after"][k].astype(np.float64) - w0) < 2e-3
+    with pytest.raises(ValueError):
+        P.fwd_computing_loss_2d(loss_mode='L1')
