@@ -124,17 +124,17 @@ def csrc_hash():
 
 
 def pmc_lookup(kernel, prec, L, H, points):
-    """(traffic bytes per launch, matrix-pipe busy fraction, source) from profiles/r03_pmc.json or Nones."""
+    """(traffic bytes per launch, matrix-pipe busy fraction, source, clock held in GHz) from profiles/r03_pmc.json or Nones."""
     try:
         doc = json.load(open(PMC_JSON))
     except Exception:
-        return None, None, None
+        return None, None, None, None
     if doc.get("csrc_hash") != csrc_hash():
-        return None, None, "profiles/r03_pmc.json was measured on another csrc/ (%s)" % doc.get("csrc_hash")
+        return None, None, "profiles/r03_pmc.json was measured on another csrc/ (%s)" % doc.get("csrc_hash"), None
     for e in doc.get("entries", []):
         if (e["kernel_short"], e["precision"], e["layers"], e["hidden"], e["points"]) == (kernel, prec, L, H, points):
-            return e.get("traffic_bytes"), e.get("mfma_busy"), "profiles/r03_pmc.json:" + e["kernel"]
-    return None, None, None
+            return e.get("traffic_bytes"), e.get("mfma_busy"), "profiles/r03_pmc.json:" + e["kernel"], e.get("clock_ghz")
+    return None, None, None, None
 
 
 def time_kernel(fn, reps):
@@ -296,7 +296,7 @@ def kernel_report(E_, args, prec, ms_step, n_local, n_global):
     dom = max(kernels, key=kernels.get)
     achieved = flops_each / (kernels[dom] * 1e-3) / 1e12
     peak = MFMA_PEAK_TFLOPS[prec]
-    traffic, pipe_busy, src = pmc_lookup(dom, prec, L, H, n_launch)
+    traffic, pipe_busy, src, clock = pmc_lookup(dom, prec, L, H, n_launch)
     step_flops = 24.0 * pw * n_local + (2.0 * weight_count(EV_NET[0], EV_NET[1], 1) * n_local if ev else 0.0)
     # second reading of the same launch: the spill traffic (PMC) against the HBM peak - what DESIGN.md 4.3 shows the
     # bf16x3 sweeps are actually limited by (null without a PMC record of this build)
@@ -305,6 +305,9 @@ def kernel_report(E_, args, prec, ms_step, n_local, n_global):
     return dict(bound="mfma", kernel=dom, achieved=achieved, peak=peak, unit="TFLOP/s", frac=achieved / peak,
                 traffic=traffic, hbm=hbm, pmc_source=src, mfma_per_product=MFMA_PER_PRODUCT[prec],
                 mfma_issue_frac=achieved * MFMA_PER_PRODUCT[prec] / peak, matrix_pipe_busy_pmc=pipe_busy,
+                # clock the kernel held in the PMC pass (GRBM_GUI_ACTIVE / 8 / duration; 2.4 GHz nominal): the bf16x3 kernels
+                # of the headline shape are held at ~1.7 GHz by board power
+                clock_ghz_pmc=clock,
                 algorithmic_flop_per_launch=flops_each,
                 kernel_ms={k: round(v, 4) for k, v in kernels.items()},
                 step_tflops=step_flops / (ms_step * 1e-3) / 1e12,

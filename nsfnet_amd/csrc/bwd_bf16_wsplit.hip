@@ -70,13 +70,17 @@ __global__ __launch_bounds__(512, 1) void bwd_wsplit_kernel(BwdArgs a) {
   // saved-activation quads in flight (24-bit format): requested SQ quads ahead, the first SQ of a phase already during
   // the last k-step of the G phase before it
   u32x4 sq[SQ + 1][3];
-  auto quad_o = [&](int qq, int hi, int h) { return 32 * (4 * (qq >> 1) + w) + 8 * ((qq & 1) + 2 * hi) + 4 * h; };
-  auto sload = [&](const float* Sl, int qq, int pp, int hi, int h) {
-    if ((qq >> 1) >= mc) return;                        // (uniform: this wave owns no block in that region)
-    const unsigned so = (unsigned)(quad_o(qq, hi, h) >> 2) * PPL + pp;
+  // Items of a phase in processing order (fwd_bf16_wsplit.hip: the last block's two quads ride in quarters 0 and 1):
+  //   quarter 0: (block 0, quad 0) (0, 1) (MQ-1, 0) | quarter 1: (1, 0) (1, 1) (MQ-1, 1) | quarter q >= 2: (q, 0) (q, 1) | last: none
+  auto item_bq = [](int i) { return i < 6 ? ((i % 3) == 2 ? MQ - 1 : i / 3) : 2 + (i - 6) / 2; };
+  auto item_k = [](int i) { return i < 6 ? ((i % 3) == 2 ? i / 3 : i % 3) : (i - 6) % 2; };
+  auto quad_o = [&](int bq, int k, int hi, int h) { return 32 * (4 * bq + w) + 8 * (k + 2 * hi) + 4 * h; };
+  auto sload = [&](const float* Sl, int i, int pp, int hi, int h) {
+    if (item_bq(i) >= mc) return;                       // (uniform: this wave owns no block in the last region)
+    const unsigned so = (unsigned)(quad_o(item_bq(i), item_k(i), hi, h) >> 2) * PPL + pp;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      sq[qq % (SQ + 1)][k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + k * PLQ) + so));
+      sq[i % (SQ + 1)][k] = __builtin_bit_cast(u32x4, __builtin_nontemporal_load(pin_base(reinterpret_cast<const f32x4*>(Sl) + k * PLQ) + so));
   };
   auto unpack_plane = [&](const u32x4 (&pk)[3], int p) {
     return unpack24(u32x2{pk[p >> 1][2 * (p & 1)], pk[p >> 1][2 * (p & 1) + 1]}, pk[2][p]);
@@ -191,105 +195,131 @@ __global__ __launch_bounds__(512, 1) void bwd_wsplit_kernel(BwdArgs a) {
 #pragma unroll
       for (int qq = 0; qq < SQ; ++qq) sload(Sl, qq, pp, hi, h);
     }
+    auto swaps = [&](int bq) {      // the four streams of a point into one lane (fwd_bf16_wsplit.hip)
 #pragma unroll
-    for (int q = 0; q < MQ; ++q) {
-      const bool have = q < mc;
-      const bool prev = q > 0 && !last;
-      const int b = 4 * q + w;
-      if (have && !first) {      // the four streams of a point into one lane (fwd_bf16_wsplit.hip)
+      for (int r = 0; r < 8; ++r) {
+        auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[bq][0][r]), __float_as_uint(acc[bq][0][r + 8]), false, false);
+        auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[bq][1][r]), __float_as_uint(acc[bq][1][r + 8]), false, false);
+        acc[bq][0][r] = __uint_as_float(s01[0]); acc[bq][0][r + 8] = __uint_as_float(s01[1]);
+        acc[bq][1][r] = __uint_as_float(s23[0]); acc[bq][1][r + 8] = __uint_as_float(s23[1]);
+      }
+    };
+    // item i = quad k of block bq: z-bar of its four features x four streams, skinny-gradient column sums
+    auto compute = [&](int i, f32x4 (&zq)[4]) {
+      const int bq = item_bq(i), k = item_k(i), o = quad_o(bq, k, hi, h);
+      f32x4 sc[4];
+      if (last) {
+        // layer 0: same two FMAs and tanh as the forward, bit for bit
+        const f32x4 wx4 = *reinterpret_cast<const f32x4*>(w0G + o), wy4 = *reinterpret_cast<const f32x4*>(w0G + HP + o);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(w0G + 2 * HP + o);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[q][0][r]), __float_as_uint(acc[q][0][r + 8]), false, false);
-          auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[q][1][r]), __float_as_uint(acc[q][1][r + 8]), false, false);
-          acc[q][0][r] = __uint_as_float(s01[0]); acc[q][0][r + 8] = __uint_as_float(s01[1]);
-          acc[q][1][r] = __uint_as_float(s23[0]); acc[q][1][r + 8] = __uint_as_float(s23[1]);
-        }
+        for (int e = 0; e < 4; ++e) sc[0][e] = fast_tanh(fmaf(wx4[e], pxE, fmaf(wy4[e], pyE, b4[e])));
+        sc[1] = wx4; sc[2] = wy4; sc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sc[p] = unpack_plane(sq[i % (SQ + 1)], p);
+      }
+      f32x4 wov[3], dwv[2], wo4[3];
+      if (first) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wo4[c] = *reinterpret_cast<const f32x4*>(woutG + c * HP + o);
       }
 #pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * k + e;
+        float ga, gx, gy, gd;
+        if (first) {      // adjoint of the last hidden layer's a-streams: rank-3 update from the output adjoints
+          ga = wo4[0][e] * oc[0][0] + wo4[1][e] * oc[1][0] + wo4[2][e] * oc[2][0];
+          gx = wo4[0][e] * oc[0][1] + wo4[1][e] * oc[1][1] + wo4[2][e] * oc[2][1];
+          gy = wo4[0][e] * oc[0][2] + wo4[1][e] * oc[1][2] + wo4[2][e] * oc[2][2];
+          gd = wo4[0][e] * oc[0][3] + wo4[1][e] * oc[1][3] + wo4[2][e] * oc[2][3];
+        } else {
+          ga = acc[bq][0][r]; gx = acc[bq][0][r + 8]; gy = acc[bq][1][r]; gd = acc[bq][1][r + 8];
+        }
+        const float t = sc[0][e], zx = sc[1][e], zy = sc[2][e], zd = sc[3][e];
+        const float d1 = 1.f - t * t;
+        const float d2 = -2.f * t * d1;
+        const float d3 = -2.f * d1 * (1.f - 3.f * t * t);
+        const float zz = zx * zx + zy * zy;
+        zq[1][e] = d1 * gx + 2.f * d2 * zx * gd;
+        zq[2][e] = d1 * gy + 2.f * d2 * zy * gd;
+        zq[3][e] = d1 * gd;
+        zq[0][e] = d1 * ga + d2 * (zx * gx + zy * gy) + (d3 * zz + d2 * zd) * gd;
+        if (first) {      // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
+          const float ax = d1 * zx, ay = d1 * zy, ad = d2 * zz + d1 * zd;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) wov[c][e] = oc[c][0] * t + oc[c][1] * ax + oc[c][2] * ay + oc[c][3] * ad;
+        }
+        if (last) { dwv[0][e] = zq[0][e] * pxE + zq[1][e]; dwv[1][e] = zq[0][e] * pyE + zq[2][e]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // column sums over the 16 points of a lane row, four features at once (reduce_util.h)
+      commit(sg_db(HP, lE), o, sum_cols4<16>(zq[0][0], zq[0][1], zq[0][2], zq[0][3], lane));
+      if (first) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          commit(sg_wout(HP, L) + c * HP, o, sum_cols4<16>(wov[c][0], wov[c][1], wov[c][2], wov[c][3], lane));
+      }
+      if (last) {
+        commit(sg_w0x(HP, L), o, sum_cols4<16>(dwv[0][0], dwv[0][1], dwv[0][2], dwv[0][3], lane));
+        commit(sg_w0y(HP, L), o, sum_cols4<16>(dwv[1][0], dwv[1][1], dwv[1][2], dwv[1][3], lane));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // hi/lo split of z-bar (parked in st[k], or straight into this group's copy of the last region) and its 24-bit spill
+    auto finish = [&](int i, f32x4 (&zq)[4], bool direct) {
+      const int bq = item_bq(i), k = item_k(i), o = quad_o(bq, k, hi, h);
+      const unsigned so = (unsigned)(o >> 2) * PPL + pp;
+      u32x4 pk[3];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (direct) {
+          u32x2 th, tl;
+          split4(zq[p][0], zq[p][1], zq[p][2], zq[p][3], th, tl);
+          const int off = XI::chunk_off(pp, img_chunk(o - 4 * h, grp)) + 8 * h;
+          *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = th;
+          if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = tl;
+        } else {
+          split4(zq[p][0], zq[p][1], zq[p][2], zq[p][3], st[k][p][0], st[k][p][1]);
+        }
+        u32x2 hi24; unsigned lo24;      // 24-bit spill (bf16_util.h pack24): three 16-byte planes
+        pack24(zq[p], hi24, lo24);
+        pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
+        if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Zl) + (p >> 1) * PLQ) + so);
+        if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Zl) + 2 * PLQ) + so);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < MQ; ++q) {
+      const bool mainb = q < MQ - 1;                     // blocks 0 .. MQ - 2 ride in their own quarter (every wave owns them)
+      const bool prev = q > 0 && !last;                  // block q - 1 is parked and its region is free now
+      const bool extra = q < 2 && mc == MQ;              // the last block's quads ride in quarters 0 and 1 (uniform)
+      const int i0 = q < 2 ? 3 * q : 6 + 2 * (q - 2);    // first item of this quarter
+      if (mainb && !first) swaps(q);
+      if (q == 0 && mc == MQ && !first) swaps(MQ - 1);
+#pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int qq = 2 * q + k, o = quad_o(qq, hi, h);
-        if (!last && qq + SQ < NQD) sload(Sl, qq + SQ, pp, hi, h);
+        const int i = i0 + k;
+        if (mainb && !last && i + SQ < NQD) sload(Sl, i + SQ, pp, hi, h);
         // first weight k-step of the G phase that follows (its first MFMA would otherwise wait out an L2 round trip)
-        if (!last && qq == NQD - 1) wload(lE, 0, lane);
+        if (!last && q == MQ - 1 && k == 1) wload(lE, 0, lane);
         f32x4 zq[4];
-        if (have) {
-          f32x4 sc[4];
-          if (last) {
-            // layer 0: same two FMAs and tanh as the forward, bit for bit
-            const f32x4 wx4 = *reinterpret_cast<const f32x4*>(w0G + o), wy4 = *reinterpret_cast<const f32x4*>(w0G + HP + o);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(w0G + 2 * HP + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sc[0][e] = fast_tanh(fmaf(wx4[e], pxE, fmaf(wy4[e], pyE, b4[e])));
-            sc[1] = wx4; sc[2] = wy4; sc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-          } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) sc[p] = unpack_plane(sq[qq % (SQ + 1)], p);
-          }
-          f32x4 wov[3], dwv[2], wo4[3];
-          if (first) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) wo4[c] = *reinterpret_cast<const f32x4*>(woutG + c * HP + o);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * k + e;
-            float ga, gx, gy, gd;
-            if (first) {      // adjoint of the last hidden layer's a-streams: rank-3 update from the output adjoints
-              ga = wo4[0][e] * oc[0][0] + wo4[1][e] * oc[1][0] + wo4[2][e] * oc[2][0];
-              gx = wo4[0][e] * oc[0][1] + wo4[1][e] * oc[1][1] + wo4[2][e] * oc[2][1];
-              gy = wo4[0][e] * oc[0][2] + wo4[1][e] * oc[1][2] + wo4[2][e] * oc[2][2];
-              gd = wo4[0][e] * oc[0][3] + wo4[1][e] * oc[1][3] + wo4[2][e] * oc[2][3];
-            } else {
-              ga = acc[q][0][r]; gx = acc[q][0][r + 8]; gy = acc[q][1][r]; gd = acc[q][1][r + 8];
-            }
-            const float t = sc[0][e], zx = sc[1][e], zy = sc[2][e], zd = sc[3][e];
-            const float d1 = 1.f - t * t;
-            const float d2 = -2.f * t * d1;
-            const float d3 = -2.f * d1 * (1.f - 3.f * t * t);
-            const float zz = zx * zx + zy * zy;
-            zq[1][e] = d1 * gx + 2.f * d2 * zx * gd;
-            zq[2][e] = d1 * gy + 2.f * d2 * zy * gd;
-            zq[3][e] = d1 * gd;
-            zq[0][e] = d1 * ga + d2 * (zx * gx + zy * gy) + (d3 * zz + d2 * zd) * gd;
-            if (first) {      // dWout[c][o] += sum_s oadj[c][s] * a_s[o]
-              const float ax = d1 * zx, ay = d1 * zy, ad = d2 * zz + d1 * zd;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) wov[c][e] = oc[c][0] * t + oc[c][1] * ax + oc[c][2] * ay + oc[c][3] * ad;
-            }
-            if (last) { dwv[0][e] = zq[0][e] * pxE + zq[1][e]; dwv[1][e] = zq[0][e] * pyE + zq[2][e]; }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          // column sums over the 16 points of a lane row, four features at once (reduce_util.h)
-          commit(sg_db(HP, lE), o, sum_cols4<16>(zq[0][0], zq[0][1], zq[0][2], zq[0][3], lane));
-          if (first) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              commit(sg_wout(HP, L) + c * HP, o, sum_cols4<16>(wov[c][0], wov[c][1], wov[c][2], wov[c][3], lane));
-          }
-          if (last) {
-            commit(sg_w0x(HP, L), o, sum_cols4<16>(dwv[0][0], dwv[0][1], dwv[0][2], dwv[0][3], lane));
-            commit(sg_w0y(HP, L), o, sum_cols4<16>(dwv[1][0], dwv[1][1], dwv[1][2], dwv[1][3], lane));
-          }
+        if (mainb) compute(i, zq);
+        // block q - 1, parked in the previous quarter: its region is free now; quad k leaves its registers before the refill
+        if (prev) dump_k(4 * (q - 1) + w, k, pp, hi, h);
+        if (mainb && !last) finish(i, zq, false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (q < 2) {
+        const int i = i0 + 2;
+        if (!last && i + SQ < NQD) sload(Sl, i + SQ, pp, hi, h);
+        if (extra) {
+          f32x4 zq[4];
+          compute(i, zq);
+          if (!last) finish(i, zq, true);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // block q - 1, parked in the previous quarter: its region is free now; quad k leaves its registers before the refill
-        if (prev) dump_k(b - 4, k, pp, hi, h);
-        if (have && !last) {
-          const unsigned so = (unsigned)(o >> 2) * PPL + pp;
-          u32x4 pk[3];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            split4(zq[p][0], zq[p][1], zq[p][2], zq[p][3], st[k][p][0], st[k][p][1]);
-            u32x2 hi24; unsigned lo24;      // 24-bit spill (bf16_util.h pack24): three 16-byte planes
-            pack24(zq[p], hi24, lo24);
-            pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
-            if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Zl) + (p >> 1) * PLQ) + so);
-            if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Zl) + 2 * PLQ) + so);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if (q == MQ - 1) dump_k(b, k, pp, hi, h);      // the last region has a copy per group: written in place
-        }
-        __builtin_amdgcn_sched_barrier(0);
       }
       if (last && q == MQ - 1 && next_tile >= 0) seeds(next_tile, pxN, pyN);      // the group's next tile: its output adjoints
       __syncthreads();

@@ -15,7 +15,10 @@
 // second copy of that (short) region, and each group keeps its own copy - a group's E phase writes its last block
 // straight into its copy while the other group's M phase reads the other one.  (The hidden-256 kernel parks it through
 // the first quarter of the following M phase; here those 32 registers are the second half of the weight ring: four
-// feature blocks per wave need 64 registers of weight fragments for two k-steps.)
+// feature blocks per wave need 64 registers of weight fragments for two k-steps.)  Being private, that copy can be
+// written at ANY time of the E phase: the last block's two quads are computed in quarters 0 and 1 (three quads per
+// quarter there), and the last quarter - in which the M group has only the short last region to multiply - carries
+// nothing but the dump of block MQ - 2.  (Measured neutral at 8x400: the wide sweeps wait on their weight stream.)
 //
 // A 64-column accumulator block holds two streams (lanes 0-15 / 16-31): v_permlane16_swap brings the four streams
 // of a point into one lane (fwd_bf16_wide.hip), so lane (pp, hi, h) of a wave ends up with the eight features
@@ -184,79 +187,99 @@ __global__ __launch_bounds__(512, 1) void fwd_wsplit_kernel(FwdArgs a) {
       }
       if (pstage_tile >= 0 && pstage_tile < a.ntiles && q == 1)
         residual_point_stage<PPL, COLS>(a, outvG, pstage_tile, gtid, npad, lsum);
-      const bool have = q < mc;                          // this wave owns a block in region q (uniform)
-      const bool prev = q > 0 && !last;                  // block q - 1 (always owned) is parked and its region is free now
-      const int b = 4 * q + w;
-      if (have) {
-        // the four streams of a point into one lane (see the header)
-        if (!first) {
+      // Blocks 0 .. MQ - 2 (every wave owns them) ride in their own quarter.  The LAST block's two quads ride in quarters
+      // 0 and 1 instead of a quarter of their own: its region has a per-group copy that nobody else touches during this
+      // phase, so it can be written at any time - and the last quarter, where the M group has only the short last
+      // region to multiply (2 k-steps at hidden 416), is left with the dump of block MQ - 2 alone.
+      const bool mainb = q < MQ - 1;
+      const bool prev = q > 0 && !last;                  // block q - 1 is parked and its region is free now
+      const bool extra = q < 2 && mc == MQ;              // (uniform: this wave owns a block in the last region)
+      auto swaps = [&](int bq) {                          // the four streams of a point into one lane (see the header)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[q][0][r]), __float_as_uint(acc[q][0][r + 8]), false, false);
-            auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[q][1][r]), __float_as_uint(acc[q][1][r + 8]), false, false);
-            acc[q][0][r] = __uint_as_float(s01[0]); acc[q][0][r + 8] = __uint_as_float(s01[1]);
-            acc[q][1][r] = __uint_as_float(s23[0]); acc[q][1][r + 8] = __uint_as_float(s23[1]);
-          }
+        for (int r = 0; r < 8; ++r) {
+          auto s01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[bq][0][r]), __float_as_uint(acc[bq][0][r + 8]), false, false);
+          auto s23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[bq][1][r]), __float_as_uint(acc[bq][1][r + 8]), false, false);
+          acc[bq][0][r] = __uint_as_float(s01[0]); acc[bq][0][r + 8] = __uint_as_float(s01[1]);
+          acc[bq][1][r] = __uint_as_float(s23[0]); acc[bq][1][r + 8] = __uint_as_float(s23[1]);
         }
-      }
+      };
+      // chain rule of quad k of block bq: a-streams av, saved values sv
+      auto compute = [&](int bq, int k, f32x4 (&av)[4], f32x4 (&sv)[4]) {
+        const int o = 32 * (4 * bq + w) + 8 * (k + 2 * hi) + 4 * h;
+        f32x4 b4, wx4, wy4;
+        if (first) {
+          wx4 = *reinterpret_cast<const f32x4*>(w0L + o); wy4 = *reinterpret_cast<const f32x4*>(w0L + HP + o);
+          b4 = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
+        } else {
+          b4 = *reinterpret_cast<const f32x4*>(bE + o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * k + e;
+          float z, zx, zy, zd;
+          if (first) {
+            z = fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e])); zx = wx4[e]; zy = wy4[e]; zd = 0.f;
+          } else {
+            z = acc[bq][0][r] + b4[e]; zx = acc[bq][0][r + 8]; zy = acc[bq][1][r]; zd = acc[bq][1][r + 8];
+          }
+          const float t = fast_tanh(z);
+          const float d1 = 1.f - t * t;
+          const float d2 = -2.f * t * d1;
+          av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
+          sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // hi/lo split of the a-streams (parked in st[k], or straight into the image: `direct`), output layer (last), S spill
+      auto finish = [&](int bq, int k, f32x4 (&av)[4], f32x4 (&sv)[4], bool direct) {
+        const int o = 32 * (4 * bq + w) + 8 * (k + 2 * hi) + 4 * h;
+        const unsigned so = (unsigned)(o >> 2) * PPL + pp;
+        u32x4 pk[3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (!last) {
+            if (direct) {
+              u32x2 th, tl;
+              split4(av[p][0], av[p][1], av[p][2], av[p][3], th, tl);
+              const int off = XI::chunk_off(pp, img_chunk(o - 4 * h, grp)) + 8 * h;
+              *reinterpret_cast<u32x2*>(X + p * XI::PLANE * 2 + off) = th;
+              if (TERMS == 3) *reinterpret_cast<u32x2*>(X + XI::HALF * 2 + p * XI::PLANE * 2 + off) = tl;
+            } else {
+              split4(av[p][0], av[p][1], av[p][2], av[p][3], st[k][p][0], st[k][p][1]);
+            }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const f32x4 wo = *reinterpret_cast<const f32x4*>(woutL + c * HP + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) po[c][p] = fmaf(wo[e], av[p][e], po[c][p]);
+            }
+          }
+          u32x2 hi24; unsigned lo24;      // 24-bit spill (bf16_util.h pack24): three 16-byte planes
+          pack24(sv[p], hi24, lo24);
+          pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
+          if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Sl) + (p >> 1) * PLQ) + so);
+          if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Sl) + 2 * PLQ) + so);
+          if (last) asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (mainb && !first) swaps(q);
+      if (q == 0 && mc == MQ && !first) swaps(MQ - 1);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int o = 32 * b + 8 * (k + 2 * hi) + 4 * h;
         if (!last && q == MQ - 1 && k == 1) wload_l(lE + 1, 0, lane);      // first weight k-step of M_{lE+1}
         f32x4 av[4], sv[4];
-        if (have) {
-          f32x4 b4, wx4, wy4;
-          if (first) {
-            wx4 = *reinterpret_cast<const f32x4*>(w0L + o); wy4 = *reinterpret_cast<const f32x4*>(w0L + HP + o);
-            b4 = *reinterpret_cast<const f32x4*>(w0L + 2 * HP + o);
-          } else {
-            b4 = *reinterpret_cast<const f32x4*>(bE + o);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * k + e;
-            float z, zx, zy, zd;
-            if (first) {
-              z = fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e])); zx = wx4[e]; zy = wy4[e]; zd = 0.f;
-            } else {
-              z = acc[q][0][r] + b4[e]; zx = acc[q][0][r + 8]; zy = acc[q][1][r]; zd = acc[q][1][r + 8];
-            }
-            const float t = fast_tanh(z);
-            const float d1 = 1.f - t * t;
-            const float d2 = -2.f * t * d1;
-            av[0][e] = t; av[1][e] = d1 * zx; av[2][e] = d1 * zy; av[3][e] = d2 * (zx * zx + zy * zy) + d1 * zd;
-            sv[0][e] = t; sv[1][e] = zx; sv[2][e] = zy; sv[3][e] = zd;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+        if (mainb) compute(q, k, av, sv);
         // block q - 1, parked in the previous quarter: quad k leaves its registers just before they are refilled
-        if (prev) dump_k(b - 4, k, pp, hi, h);
-        if (have) {
-          const unsigned so = (unsigned)(((o - 4 * h) >> 2) + h) * PPL + pp;
-          u32x4 pk[3];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (!last) {
-              split4(av[p][0], av[p][1], av[p][2], av[p][3], st[k][p][0], st[k][p][1]);
-            } else {
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                const f32x4 wo = *reinterpret_cast<const f32x4*>(woutL + c * HP + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) po[c][p] = fmaf(wo[e], av[p][e], po[c][p]);
-              }
-            }
-            u32x2 hi24; unsigned lo24;      // 24-bit spill (bf16_util.h pack24): three 16-byte planes
-            pack24(sv[p], hi24, lo24);
-            pk[p >> 1][2 * (p & 1)] = hi24[0]; pk[p >> 1][2 * (p & 1) + 1] = hi24[1]; pk[2][p] = lo24;
-            if (p & 1) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[p >> 1]), pin_base(reinterpret_cast<const f32x4*>(Sl) + (p >> 1) * PLQ) + so);
-            if (p == 3) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pk[2]), pin_base(reinterpret_cast<const f32x4*>(Sl) + 2 * PLQ) + so);
-            if (last) asm volatile("" : "+v"(po[0][p]), "+v"(po[1][p]), "+v"(po[2][p]));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          // the last region has a copy per group: written in place, nothing parked
-          if (!last && q == MQ - 1) dump_k(b, k, pp, hi, h);
-        }
+        if (prev) dump_k(4 * (q - 1) + w, k, pp, hi, h);
+        if (mainb) finish(q, k, av, sv, false);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (extra) {
+        f32x4 av[4], sv[4];
+        compute(MQ - 1, q, av, sv);
+        finish(MQ - 1, q, av, sv, true);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (last && q == MQ - 1) {

@@ -5,5 +5,12 @@
 K=$1; SCALE=${2:-0.30}
 RES=""; [ "$K" -gt 1 ] && RES="--resume experiments/conv_c4_ckpt"
 [ "$K" -gt 1 ] && mkdir -p gpurun_out/conv_c4 && cp experiments/conv_c4_ckpt/stages.jsonl gpurun_out/conv_c4/ 2>/dev/null
-NSFNET_PRECISION=bf16x3 timeout -k 10 1150 python scripts/converge_ev.py --re 4000 --dns tests/golden/dns/cavity_Re4000_384_Uniform.mat \
-  --out gpurun_out/conv_c4 --first $K --last $K --epochs-scale $SCALE --nf 250000 --layers 6 --hidden 256 $RES 2>&1 | grep -E "STAGE|Error|rror" | tail -5
+mkdir -p gpurun_out/conv_c4
+# (unbuffered and un-piped: the box kills a command that writes nothing for 7 minutes)
+NSFNET_PRECISION=bf16x3 timeout -k 10 1150 python -u scripts/converge_ev.py --re 4000 --dns tests/golden/dns/cavity_Re4000_384_Uniform.mat \
+  --out gpurun_out/conv_c4 --first $K --last $K --epochs-scale $SCALE --nf 250000 --layers 6 --hidden 256 $RES > gpurun_out/conv_c4/log_stage$K.txt 2>&1 &
+PID=$!
+while kill -0 $PID 2>/dev/null; do sleep 60; echo "[conv_c4 stage $K] $(tail -c 300 gpurun_out/conv_c4/log_stage$K.txt | tr '\n' ' ' | tail -c 200)"; done
+wait $PID; RC=$?
+grep -E "STAGE|Error u|Error v" gpurun_out/conv_c4/log_stage$K.txt | tail -4
+exit $RC

@@ -87,6 +87,51 @@ def test_host_only_entry_points(lib):
         lib.pinn_net_destroy(h)
 
 
+def test_workspace_is_sized_for_what_the_plan_writes(lib, monkeypatch):
+    """The role-split pair spills three 16-byte planes per register quad and no layer 0: its S and Z-bar are (L - 1) blocks of
+    3/4 of the classic HP x 128 floats per tile.  Every other plan keeps the classic [tile][L] blocks.  Wide nets: the
+    kernel choice (role-split at 64-column tiles for hidden 288..448, 8-wave above) does not change the workspace."""
+    for k in ("PINN_SCHED", "PINN_FWD_SCHED", "PINN_BWD_SCHED", "PINN_WSPLIT"):
+        monkeypatch.delenv(k, raising=False)
+    h = ctypes.c_void_p()
+    assert lib.pinn_net_create(3, 6, 256, ctypes.byref(h)) == 0
+    assert lib.pinn_net_set_precision(h, 1, 1, 1) == 0
+    p = ctypes.c_void_p()
+    assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p)) == 0
+    ntiles, L, HP = 360000 // 32, 6, 256
+    spill = 2 * (ntiles + 1) * (L - 1) * 3 * HP * 32 * 4               # S + Z-bar
+    total = lib.pinn_plan_workspace_bytes(p, 1)
+    assert spill <= total <= spill + 200 * 1024 * 1024, (spill, total)     # + dW slabs, skinny accumulators, partials
+    assert total < 11.4e9
+    lib.pinn_plan_destroy(p)
+    monkeypatch.setenv("PINN_SCHED", "0")                                   # classic layout: 4 planes x L layers
+    assert lib.pinn_plan_create(h, 360000, 4, ctypes.byref(p)) == 0
+    classic = lib.pinn_plan_workspace_bytes(p, 1)
+    assert classic >= 2 * (ntiles + 1) * L * HP * 128 * 4 > 1.55 * spill
+    lib.pinn_plan_destroy(p); lib.pinn_net_destroy(h)
+    monkeypatch.delenv("PINN_SCHED")
+    sizes = {}
+    for ws in ("1", "0"):
+        monkeypatch.setenv("PINN_WSPLIT", ws)
+        assert lib.pinn_net_create(3, 8, 400, ctypes.byref(h)) == 0
+        assert lib.pinn_net_set_precision(h, 1, 1, 1) == 0
+        assert lib.pinn_plan_create(h, 500000, 4, ctypes.byref(p)) == 0
+        names = [lib.pinn_plan_kernel(p, k) for k in (0, 1, 2)]
+        assert names == ([b"fwd_wsplit_kernel", b"bwd_wsplit_kernel", b"dw_bf16_wide_kernel"] if ws == "1" else
+                         [b"fwd_bf16_wide_kernel", b"bwd_bf16_wide_kernel", b"dw_bf16_wide_kernel"])
+        sizes[ws] = lib.pinn_plan_workspace_bytes(p, 1)
+        lib.pinn_plan_destroy(p); lib.pinn_net_destroy(h)
+    # (the pair grid of the role-split sweeps changes the skinny-accumulator block by a few MB, nothing else)
+    assert abs(sizes["1"] - sizes["0"]) < 64 * 1024 * 1024
+    for H, want in ((480, b"fwd_bf16_wide_kernel"), (448, b"fwd_wsplit_kernel"), (288, b"fwd_wsplit_kernel")):
+        monkeypatch.setenv("PINN_WSPLIT", "1")
+        assert lib.pinn_net_create(3, 3, H, ctypes.byref(h)) == 0
+        assert lib.pinn_net_set_precision(h, 1, 1, 1) == 0
+        assert lib.pinn_plan_create(h, 1000, 4, ctypes.byref(p)) == 0
+        assert lib.pinn_plan_kernel(p, 0) == want, H
+        lib.pinn_plan_destroy(p); lib.pinn_net_destroy(h)
+
+
 def test_argument_errors_are_reported(lib):
     h = ctypes.c_void_p()
     assert lib.pinn_net_create(3, 6, 600, ctypes.byref(h)) < 0
