@@ -74,8 +74,18 @@ __global__ __launch_bounds__(HP * 2) void bwd_wide_kernel(BwdArgs a) {
           const int g = gq + 2 * hi;
           const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
           const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
-          f32x4 s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * PPL) + so), s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * PPL) + so);
-          f32x4 s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * PPL) + so), s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+          f32x4 s0, s1, s2, s3;
+          if (l == 0 && a.s0_skip) {      // not spilled: the forward's own fmaf chain and tanhf, bit for bit
+            const int o0 = ob + 8 * g + 4 * h;
+            s1 = *reinterpret_cast<const f32x4*>(P + prep_w0x(HP) + o0); s2 = *reinterpret_cast<const f32x4*>(P + prep_w0y(HP) + o0);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(P + prep_b0(HP) + o0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s0[e] = tanhf(fmaf(s1[e], px[0], fmaf(s2[e], py[0], b4[e])));
+            s3 = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            s0 = __builtin_nontemporal_load(pin_base(S4 + 0 * (HP / 4) * PPL) + so); s1 = __builtin_nontemporal_load(pin_base(S4 + 1 * (HP / 4) * PPL) + so);
+            s2 = __builtin_nontemporal_load(pin_base(S4 + 2 * (HP / 4) * PPL) + so); s3 = __builtin_nontemporal_load(pin_base(S4 + 3 * (HP / 4) * PPL) + so);
+          }
           f32x4 z0, z1, z2, z3;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

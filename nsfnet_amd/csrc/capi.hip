@@ -50,6 +50,7 @@ struct pinn_plan_s {
   int grid_f, grid_b, groups;
   int s24w;              // wide bf16 residual plan (all three kernels bf16): 24-bit three-plane spill format
   int s0_skip;           // the sweeps do not spill layer 0 (role-split pair): dw_bf16 recomputes its activations
+  int s0_skip32;         // fp32 residual plan: layer 0 not spilled, recomputed by its readers (FwdArgs::s0_skip)
   int sl0; size_t sblk;  // compact spill geometry of the role-split plans (kernels.h spill_off); sblk = 0: classic layout
   int stagger;           // $PINN_STAGGER, read once at plan creation
   int pipe_f, grid_fp;   // schedule of the forward with saved activations (0 8-wave, 1 pipelined, 2 role-split); grid of 1 / 2 (pairs of tiles)
@@ -230,6 +231,7 @@ int pinn_plan_create(pinn_net_t net, int64_t n_points, int streams, pinn_plan_t*
   // The role-split pair writes three 16-byte planes per register quad and no layer 0: its S and Z-bar are sized for
   // exactly that, (L - 1) blocks of 3/4 of the classic HP x 128 floats per tile (5.5 instead of 8.9 GB each at
   // 6x256 / 360 000 points).  Every other plan keeps the classic [tile][L][HP x columns] layout.
+  p->s0_skip32 = streams == 4 && L >= 2 && !net->prec_fwd && !net->prec_bwd && !net->prec_dw && env_int("PINN_S0_SKIP32", 1) != 0;
   p->sl0 = p->s0_skip ? 1 : 0;
   p->sblk = p->s0_skip ? ablk / 4 * 3 : 0;
   const size_t spill_tile = p->s0_skip ? (size_t)(L - 1) * p->sblk : (size_t)L * ablk;      // floats per tile
@@ -293,7 +295,7 @@ int pinn_residual_forward(pinn_plan_t plan, void* ws, const float* prep,
   a.s24 = plan->s24w;
   a.partials = WS(plan, off_partials);
   a.stagger = plan->ntiles > 4 * plan->grid_f ? plan->stagger : 0;
-  a.sl0 = plan->sl0; a.sblk = plan->sblk;
+  a.sl0 = plan->sl0; a.sblk = plan->sblk; a.s0_skip = plan->s0_skip32;
   const bool pipe = (plan->pipe_f || plan->wsplit) && save;
   int rc = dispatch_fwd(plan, a, (hipStream_t)stream, pipe);
   if (rc) return hipfail(rc, "pinn_residual_forward");
@@ -311,7 +313,7 @@ static int run_dw_and_stash(pinn_plan_t plan, void* ws, const float* prep, const
   d.ntiles = plan->ntiles; d.L = plan->net.L; d.groups = plan->groups;
   d.slabs = WS(plan, off_slabs);
   d.configure = 0;
-  d.s0_skip = plan->s0_skip; d.s24 = plan->s24w; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
+  d.s0_skip = plan->s0_skip || plan->s0_skip32; d.s24 = plan->s24w; d.x = x; d.y = y; d.prep = prep; d.n = (int)plan->n;
   d.sl0 = plan->sl0; d.sblk = plan->sblk;
   return dispatch_dw(plan, d, s);
 }
@@ -330,7 +332,7 @@ int pinn_residual_backward_phases(pinn_plan_t plan, void* ws, const float* prep,
   for (int k = 0; k < 4; ++k) a.coef_eq[k] = coef_eq4[k];
   a.inv_re = 1.0f / Re; a.scale = coord_scale; a.ebar = ebar_out;
   a.s24 = plan->s24w;
-  a.sl0 = plan->sl0; a.sblk = plan->sblk;
+  a.sl0 = plan->sl0; a.sblk = plan->sblk; a.s0_skip = plan->s0_skip32;
   a.sg = WS(plan, off_sg);
   int rc = 0;
   if (phases & 1) {

@@ -51,11 +51,24 @@ __global__ __launch_bounds__(HP * 2) void dw_kernel(DwArgs a) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   f32x4 zr[4], sr[4];
+  const bool rec = NS == 4 && a.s0_skip && l == 1;      // (uniform per workgroup)
+  f32x4 wx4 = {0.f, 0.f, 0.f, 0.f}, wy4 = wx4, b4 = wx4;
+  if (rec) {
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(a.prep + prep_w0x(HP));
+    wx4 = w0[og]; wy4 = w0[HP / 4 + og]; b4 = w0[2 * (HP / 4) + og];
+  }
   auto gload = [&](int ch) {
     const int tile = t0 + (ch >> 2), c = ch & 3;
     const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * act_block(HP)) + 8 * c;
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * act_block(HP)) + 8 * c;
     const unsigned lo_ = (unsigned)(og * 32 + p);
+    if (rec) {      // layer-1 workgroups, layer 0 not spilled (DwArgs::s0_skip): only the point travels
+#pragma unroll
+      for (int s = 0; s < 4; ++s) zr[s] = __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * 32) + lo_);
+      const int pt = tile * 32 + 8 * c + p;
+      sr[0][0] = pt < a.n ? a.x[pt] : 0.f; sr[0][1] = pt < a.n ? a.y[pt] : 0.f;
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       zr[s] = __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * 32) + lo_);
@@ -64,7 +77,15 @@ __global__ __launch_bounds__(HP * 2) void dw_kernel(DwArgs a) {
   };
   auto lstore = [&](int buf) {
     f32x4 a0, a1, a2, a3;
-    if (NS == 4) {
+    if (rec) {      // the forward's own fmaf chain and tanhf (fwd.hip layer 0), bit for bit
+      const float px = sr[0][0], py = sr[0][1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = tanhf(fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e]))), zx = wx4[e], zy = wy4[e];
+        float d1 = 1.f - t * t, d2 = -2.f * t * d1;
+        a0[e] = t; a1[e] = d1 * zx; a2[e] = d1 * zy; a3[e] = d2 * (zx * zx + zy * zy) + d1 * 0.f;
+      }
+    } else if (NS == 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = sr[0][e], zx = sr[1][e], zy = sr[2][e], zd = sr[3][e];

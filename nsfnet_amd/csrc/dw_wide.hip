@@ -32,11 +32,24 @@ __global__ __launch_bounds__(512) void dw_wide_kernel(DwArgs a, int HP) {
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
   f32x4 zr[4], sr[4];
+  const bool rec = NS == 4 && a.s0_skip && l == 1;      // layer-1 workgroups, layer 0 not spilled (uniform per workgroup)
+  f32x4 wx4 = {0.f, 0.f, 0.f, 0.f}, wy4 = wx4, b4 = wx4;
+  if (rec && va) {
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(a.prep + prep_w0x(HP));
+    wx4 = w0[oga]; wy4 = w0[HP / 4 + oga]; b4 = w0[2 * (HP / 4) + oga];
+  }
   auto gload = [&](int ch) {
     const int tile = t0 + ch / (PPL / 8), c = ch % (PPL / 8);
     const f32x4* Zg = reinterpret_cast<const f32x4*>(a.Zb + ((size_t)tile * a.L + l) * blk) + 8 * c;
     const f32x4* Sg = reinterpret_cast<const f32x4*>(a.S + ((size_t)tile * a.L + (l - 1)) * blk) + 8 * c;
     const unsigned loz = (unsigned)(ogz * PPL + p), loa = (unsigned)(oga * PPL + p);
+    if (rec) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) zr[s] = vz ? __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + loz) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int pt = tile * PPL + 8 * c + p;
+      sr[0][0] = pt < a.n ? a.x[pt] : 0.f; sr[0][1] = pt < a.n ? a.y[pt] : 0.f;
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       zr[s] = vz ? __builtin_nontemporal_load(pin_base(Zg + (size_t)s * (HP / 4) * PPL) + loz) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -45,7 +58,15 @@ __global__ __launch_bounds__(512) void dw_wide_kernel(DwArgs a, int HP) {
   };
   auto lstore = [&](int buf) {
     f32x4 a0, a1, a2, a3;
-    if (NS == 4) {
+    if (rec) {      // the forward's own fmaf chain and tanhf (fwd_wide.hip layer 0), bit for bit; padded features: all zero
+      const float px = sr[0][0], py = sr[0][1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = va ? tanhf(fmaf(wx4[e], px, fmaf(wy4[e], py, b4[e]))) : 0.f, zx = wx4[e], zy = wy4[e];
+        float d1 = 1.f - t * t, d2 = -2.f * t * d1;
+        a0[e] = t; a1[e] = d1 * zx; a2[e] = d1 * zy; a3[e] = d2 * (zx * zx + zy * zy);
+      }
+    } else if (NS == 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = sr[0][e], zx = sr[1][e], zy = sr[2][e], zd = sr[3][e];

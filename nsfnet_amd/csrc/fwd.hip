@@ -86,7 +86,7 @@ __global__ __launch_bounds__(HP * 2) void fwd_kernel(FwdArgs a) {
             s0[e] = t0; s1[e] = t1; s2[e] = t2; s3[e] = t3;
           }
         }
-        if (Sl) {
+        if (Sl && !(NS == 4 && l == 0 && a.s0_skip)) {      // (layer 0 is recomputed by its readers: FwdArgs::s0_skip)
           const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * 32 + col);
           const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
           __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * 32) + so);   // streamed once: nontemporal

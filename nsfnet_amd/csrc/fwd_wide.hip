@@ -91,7 +91,7 @@ __global__ __launch_bounds__(HP * 2) void fwd_wide_kernel(FwdArgs a) {
             Xo[48] = d2 * (zx * zx + zy * zy) + d1 * zd;
             s0[e] = t; s1[e] = zx; s2[e] = zy; s3[e] = zd;
           }
-          if (Sl) {
+          if (Sl && !(l == 0 && a.s0_skip)) {      // (layer 0 is recomputed by its readers: FwdArgs::s0_skip)
             const unsigned so = (unsigned)(((ob >> 2) + 2 * g + h) * PPL + pp);
             const f32x4* S4 = reinterpret_cast<const f32x4*>(Sl);
             __builtin_nontemporal_store(s0, pin_base(S4 + 0 * (HP / 4) * PPL) + so);

@@ -49,6 +49,10 @@ struct FwdArgs {
   // role-split sweeps (compact spill): block (tile, layer l) of S / Z-bar starts at ((size_t)tile * (L - sl0) + (l - sl0)) * sblk
   // floats - only what the sweeps write is allocated: three 16-byte planes, no layer 0 (sl0 = 1)
   int sl0; size_t sblk;
+  // fp32 kernels, residual mode: layer 0's saved activations are not spilled - (tanh(w0x x + w0y y + b0), w0x, w0y, 0)
+  // are recomputed where they are read (the reverse sweep's layer-0 epilogue, the layer-1 workgroups of the dW kernel)
+  // with the forward's own fmaf chain and tanhf: bit-identical, a sixth of S at six layers neither written nor read twice
+  int s0_skip;
 };
 // float offset of the spill block of (tile, layer l); `sblk` == 0 selects the classic [tile][L][HP x columns] layout
 PINN_HD size_t spill_off(int tile, int l, int L, int sl0, size_t sblk, size_t classic) {
@@ -72,6 +76,7 @@ struct BwdArgs {
   int configure;         // see FwdArgs
   int s24;               // see FwdArgs
   int sl0; size_t sblk;  // see FwdArgs
+  int s0_skip;           // see FwdArgs
 };
 
 struct DwArgs {

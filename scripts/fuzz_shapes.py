@@ -12,7 +12,7 @@ xb, yb, ub, vb = (a.reshape(-1)[::64].astype(np.float32) for a in ar.cavity_boun
 worst = {}
 fail = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 24):
-    L = int(rng.randint(1, 10)); H = int(rng.choice([3, 17, 32, 50, 64, 80, 100, 128, 200, 256, 300, 400, 512]))
+    L = int(rng.randint(1, 10)); H = int(rng.choice([3, 17, 32, 50, 64, 80, 100, 128, 200, 256, 270, 300, 340, 360, 400, 440, 470, 512]))      # (257..448: the wide role-split sweeps)
     N = int(rng.randint(1, 700)); Re = float(rng.choice([100.0, 2000.0, 10000.0]))
     if L * max(H, 32) > 9 * 512 or (H > 256 and L > 8):
         continue
