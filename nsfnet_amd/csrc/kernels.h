@@ -51,7 +51,7 @@ struct FwdArgs {
   int sl0; size_t sblk;
   // fp32 kernels, residual mode: layer 0's saved activations are not spilled - (tanh(w0x x + w0y y + b0), w0x, w0y, 0)
   // are recomputed where they are read (the reverse sweep's layer-0 epilogue, the layer-1 workgroups of the dW kernel)
-  // with the forward's own fmaf chain and tanhf: bit-identical, a sixth of S at six layers neither written nor read twice
+  // with the forward's own fmaf chain and tanhf: the same values, a sixth of S at six layers neither written nor read twice
   int s0_skip;
 };
 // float offset of the spill block of (tile, layer l); `sblk` == 0 selects the classic [tile][L][HP x columns] layout

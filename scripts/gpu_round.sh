@@ -20,8 +20,9 @@ for step in "$@"; do
     pmc)   bash scripts/pmc_profile.sh bf16x3 $TAG ;;
     pmc5)  cp -f gpurun_out/pmc_$TAG/pmc.json profiles/r03_pmc.json 2>/dev/null || true      # (config 5's entries join the same record)
            bash scripts/pmc_profile.sh bf16x3 ${TAG}c5 --config 5 ;;
-    configs) for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline > gpurun_out/${TAG}_bench_config$c.json 2> gpurun_out/${TAG}_bench_config$c.err; python -c "
+    configs) for c in 1 2 4 5; do python bench.py --config $c > gpurun_out/${TAG}_bench_config$c.json 2> gpurun_out/${TAG}_bench_config$c.err; python -c "
 import json,sys; d=json.load(open('gpurun_out/${TAG}_bench_config$c.json')); print('config $c', round(d['ms_per_step'],3), 'ms', d['roofline']['kernel_ms'], round(d['roofline']['frac'],4))"; done ;;
+    fuzz)  timeout -k 10 600 python scripts/fuzz_shapes.py 3 40 > gpurun_out/${TAG}_fuzz.txt 2>&1; tail -3 gpurun_out/${TAG}_fuzz.txt ;;
     strong) python bench.py --scaling strong --steps 10 --warmup 3 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/${TAG}_bench_strong1.json 2> gpurun_out/${TAG}_bench_strong1.err; python -c "
 import json; d=json.load(open('gpurun_out/${TAG}_bench_strong1.json')); print('strong N=1', d['config']['global_points'], round(d['ms_per_step'],3), 'ms', d['value'])" ;;
     big)   python bench.py --grid 2000 --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --alt-precision "" > gpurun_out/${TAG}_bench_grid2000.json 2> gpurun_out/${TAG}_bench_grid2000.err; python -c "

@@ -111,3 +111,64 @@ def test_mixed_schedules_share_the_fp32_spill_layout(monkeypatch, fs, bs):
         out[tag] = E.grads.cpu().numpy().astype(np.float64)
     assert _rel_l2(out["mixed"], out["ref"]) < 1e-4
     assert _rel_l2(out["mixed"], _oracle_grad(flat, 5, 256, x, y, bc, 1500.0)) < 1e-4
+
+
+@pytest.mark.parametrize("H,L,N", [(128, 4, 333), (256, 3, 150), (50, 2, 40)])
+def test_fp32_layer0_recompute_matches_the_spilled_version(monkeypatch, H, L, N):
+    """fp32 mode does not spill layer 0 (FwdArgs::s0_skip): the reverse sweep and the layer-1 workgroups of the dW kernel
+    recompute (tanh(w0x x + w0y y + b0), w0x, w0y, 0) with the forward's own fmaf chain and tanhf.  The loss sums (forward
+    only) must be BITWISE those of the spilled version ($PINN_S0_SKIP32=0); the gradient agrees to fp32 rounding (the
+    compiler specialises the layer-0 epilogue for z_D = 0 and contracts a few products differently), in the narrow and in
+    the 64-column fp32 kernels."""
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PINN_S0_SKIP32", flag)
+        E, flat, x, y, bc = _engine(L, H, N, "fp32", 31)
+        E.loss_and_grad()
+        torch.cuda.synchronize()
+        out[flag] = (E.grads.cpu().numpy().copy(), E.sums.cpu().numpy().copy())
+    assert np.array_equal(out["1"][1], out["0"][1])
+    d = _rel_l2(out["1"][0], out["0"][0])
+    print("fp32 layer-0 recompute vs spill: gradient rel-L2 difference %.2e" % d)
+    assert d < 1e-6
+    ref = _oracle_grad(flat, L, H, x, y, bc, 1500.0)
+    assert _rel_l2(out["1"][0], ref) < 1e-5 and _rel_l2(out["0"][0], ref) < 1e-5
+
+
+def test_rccl_moves_the_exchange_buffer_on_this_gpu(tmp_path):
+    """One lease has one GPU, so the N > 1 step (ONE all-reduce of [grads | grads_e | 24 sums], engine.py) runs under gloo
+    in the rank-logic tests.  What CAN run here is RCCL itself: a one-rank "nccl" group (= RCCL on ROCm) created the way
+    bench.py creates it (device_id), all-reducing the engine's real exchange buffer on the launch stream behind the
+    kernels that fill it.  SUM over one rank must return the buffer unchanged; the point is that RCCL initialises and
+    launches on this box and that the buffer is a valid RCCL operand (contiguous fp32, device memory of this process)."""
+    import subprocess, sys, textwrap
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from nsfnet_amd import engine as eng
+        from oracle import autograd_ref as ar
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1, device_id=dev)
+        E = eng.PinnEngine(dev, 3, 64, 1000.0, alpha_b=10.0, alpha_e=1.0, precision="bf16x3", process_group=dist.group.WORLD, world_size=1)
+        E.net.set_flat(ar.flat_params(ar.seeded_net(3, 3, 64, seed=5)))
+        rng = np.random.RandomState(0)
+        E.set_collocation(rng.rand(500).astype(np.float32), rng.rand(500).astype(np.float32))
+        xb, yb, ub, vb = (a.reshape(-1)[::16].astype(np.float32) for a in ar.cavity_boundary())
+        E.set_boundary(xb, yb, ub, vb)
+        E.loss_and_grad()
+        before = E.flat.clone()
+        dist.all_reduce(E.flat, group=E.pg)          # the call the step makes when world_size > 1
+        torch.cuda.synchronize()
+        assert torch.equal(before, E.flat) and bool(torch.isfinite(E.flat).all())
+        print("RCCL_OK", dist.get_backend(), E.flat.numel())
+        dist.destroy_process_group()
+    """ % os.path.dirname(HERE)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RCCL_OK nccl" in out.stdout
