@@ -2,7 +2,7 @@
 per kernel name, the mean counter value per dispatch - printed as text, and with --json written as the
 machine-readable record bench.py quotes its `traffic` / `matrix_pipe_busy_pmc` from:
 
-    python scripts/pmc_summarize.py gpurun_out/pmc_<tag> [--json profiles/r02_pmc.json --precision bf16x3
+    python scripts/pmc_summarize.py gpurun_out/pmc_<tag> [--json profiles/r03_pmc.json --precision bf16x3
                                                             --layers 6 --hidden 256 --points 360000]
 
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE
