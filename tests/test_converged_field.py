@@ -96,3 +96,26 @@ def test_config4_dns_file_evaluate_and_test_on_the_385_grid(monkeypatch, tmp_pat
     u_pred = P.predict(None, (star[0], star[1]))[0]
     u_pred = u_pred.detach().cpu().numpy() if hasattr(u_pred, "detach") else np.asarray(u_pred)
     np.testing.assert_allclose(m["U_pred"].reshape(-1), u_pred.reshape(-1), rtol=0, atol=1e-6)
+
+
+def test_config4_shape_run_vs_dns(monkeypatch, tmp_path):
+    """BASELINE config 4's shape trained by THIS engine on its own data (profiles/r03_convergence_ev_config4shape_re4000.jsonl):
+    ev-NSFnet, Re = 4000, 6x256 + 4x40 nets, 250 000 LHS points (config 4's per-GPU share), SDF weights, bf16x3 on the
+    role-split kernels, six stages of the production schedule at 0.30x plus four repeats of the last one = 1.5 M steps, 144
+    GPU-minutes on one MI355X.  Relative L2 error of (u, v) against the reference's cavity_Re4000_384_Uniform.mat after each
+    slice: 63.0 -> 39.4 -> 35.0 -> 30.9 -> 27.8 -> 25.2 -> 23.1 -> 21.3 -> 19.9 -> 18.6 %, still falling 1.3 points per 150 000
+    steps at half the schedule's step count - NOT yet the "< 4 %" of the reference's README, and the test says what it
+    is: the run's own end-of-training report reproduced from the kept weights, on the 385 x 385 grid."""
+    monkeypatch.setenv("NSFNET_PRECISION", "bf16x3")
+    monkeypatch.chdir(tmp_path)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    from nsfnet_amd import ev_pinn_solver as es, cavity_data as cavity
+    P = es.PysicsInformedNeuralNetwork(
+        Re=4000, layers=6, layers_1=4, hidden_size=256, hidden_size_1=40, N_f=1000, alpha_evm=0.002,
+        net_params=os.path.join(HERE, "golden", "trained", "ev_re4000_6x256_net.pth"),
+        net_params_1=os.path.join(HERE, "golden", "trained", "ev_re4000_6x256_evm.pth"))
+    star = cavity.EvDataLoader(N_f=1000).loading_evaluate_data(os.path.join(HERE, "golden", "dns", "cavity_Re4000_384_Uniform.mat"))
+    assert star[0].shape[0] == 385 * 385
+    eu, ev, ep = P.evaluate(*star)
+    assert abs(eu - 18.61) < 0.2 and abs(ev - 18.57) < 0.2, (eu, ev)
