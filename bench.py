@@ -32,7 +32,6 @@ import argparse
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -182,12 +181,12 @@ def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children (torch.distributed.run,
     rendezvous on 127.0.0.1), pass rank 0's JSON line through, return the children's exit code.  Runs before
     anything in this process touches the GPU; the parent never execs."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this pool
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the agent binds its own free rendezvous port (no pick-then-close race with other jobs of the host)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + sys.argv[1:]
     log("starting %d ranks: %s" % (n, " ".join(cmd[1:])))
     r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = []

@@ -165,7 +165,7 @@ def test_strong_scaling_two_gloo_ranks(tmp_path):
     """ % ROOT))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29713", str(script)],
+                          "--standalone", "--local-addr", "127.0.0.1", str(script)],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "STRONG_OK 2880000 []" in out.stdout            # (no alt modes in the strong table)

@@ -4,7 +4,6 @@ per step, global-count normalisation, identical replicas after Adam.  The device
 are replaced by tests/fakes.py (oracle arithmetic on CPU); the real kernels are covered by
 the -m gpu tests."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -14,11 +13,6 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
 
 
 def _case(sup_n=9):
@@ -52,11 +46,11 @@ def _build_solver(case):
     return P
 
 
-def _run_rank(rank, world, port, out_dir, sup_n=9):
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _run_rank(rank, world, out_dir, sup_n=9):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1")
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # file rendezvous: no port to pick (a picked-then-closed port can be taken by another job of the host)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(out_dir, "rendezvous"), rank=rank, world_size=world)
     try:
         P = _build_solver(_case(sup_n))
         assert P.is_distributed and P.engine.world_size == world
@@ -74,8 +68,7 @@ def _run_rank(rank, world, port, out_dir, sup_n=9):
 @pytest.mark.timeout(300)
 def test_two_rank_sharded_training_matches_single_process(tmp_path, monkeypatch):
     world = 2
-    port = _free_port()
-    mp.spawn(_run_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_run_rank, args=(world, str(tmp_path)), nprocs=world, join=True)
     r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world))
     # shards: contiguous blocks, last rank takes the remainder; supervised = np.array_split
     assert (int(r0["n_f_local"]), int(r1["n_f_local"])) == (35, 35)
@@ -103,8 +96,7 @@ def test_rank_with_empty_supervised_share(tmp_path, monkeypatch):
     (ev-NSFnet/pinn_solver.py:219-221, the branch is then skipped there, :400).  That rank must still
     take part in the step's all-reduce and normalise by the global counts - not raise, not hang."""
     world = 2
-    port = _free_port()
-    mp.spawn(_run_rank, args=(world, port, str(tmp_path), 1), nprocs=world, join=True)
+    mp.spawn(_run_rank, args=(world, str(tmp_path), 1), nprocs=world, join=True)
     r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world))
     assert (int(r0["n_s_local"]), int(r1["n_s_local"])) == (1, 0)
     np.testing.assert_array_equal(r0["params"], r1["params"])
