@@ -74,13 +74,17 @@ def mm(A, B, mode):
 def mm_dw(Zs, As, mode, tile):
     """sum over the four streams of Z_s^T (H_out, N) @ A_s (N, H_in): K = points x streams.
     i8x2: block scales per feature, stream and tile of points (one i32 accumulation per stream and tile);
+    i8x2jn: ONE i32 accumulation per tile over all four streams, one scale per feature, nothing else;
     i8x2j: ONE i32 accumulation per tile over all four streams - each stream of A is first scaled to unit maximum over
     the tile and the matching stream of Z by the inverse (free: the product is unchanged), then one scale per feature."""
     if mode in ("exact", "fp32", "bf16", "bf16x3"):
         return sum(mm(Zs[s].T, As[s], mode) for s in range(4))
     out = 0.0
     for p0 in range(0, Zs[0].shape[0], tile):
-        if mode == "i8x2j":
+        if mode == "i8x2jn":                                    # joint accumulation WITHOUT the per-stream normalisation
+            out = out + mm(np.concatenate([Zs[s][p0:p0 + tile] for s in range(4)], axis=0).T,
+                           np.concatenate([As[s][p0:p0 + tile] for s in range(4)], axis=0), "i8x2")
+        elif mode == "i8x2j":
             c = [max(float(np.max(np.abs(As[s][p0:p0 + tile]))), 1e-300) for s in range(4)]
             Zt = np.concatenate([Zs[s][p0:p0 + tile] * c[s] for s in range(4)], axis=0)
             At = np.concatenate([As[s][p0:p0 + tile] / c[s] for s in range(4)], axis=0)
@@ -164,7 +168,7 @@ def main():
     modes = [("fp32", "fp32", "fp32"), ("bf16x3", "bf16x3", "bf16x3"), ("bf16", "bf16", "bf16"),
              ("i8x2", "i8x2", "bf16x3"), ("i8x2f", "i8x2f", "bf16x3"), ("i8x3", "i8x3", "bf16x3"),
              ("i8x2", "bf16x3", "bf16x3"), ("bf16x3", "i8x2", "bf16x3"),
-             ("bf16x3", "bf16x3", "i8x2"), ("bf16x3", "bf16x3", "i8x2j"), ("bf16x3", "i8x2", "i8x2"), ("bf16x3", "i8x2", "i8x2j"),
+             ("bf16x3", "bf16x3", "i8x2"), ("bf16x3", "bf16x3", "i8x2j"), ("bf16x3", "bf16x3", "i8x2jn"), ("bf16x3", "i8x2", "i8x2"), ("bf16x3", "i8x2", "i8x2j"),
              ("bf16x3", "i8a3b2", "bf16x3"), ("bf16x3", "i8a2b3", "bf16x3"), ("i8a3b2", "bf16x3", "bf16x3"), ("i8a2b3", "bf16x3", "bf16x3"),
              ("bf16x3", "bf16x3", "bf16")]
     for name, flat in sets:
