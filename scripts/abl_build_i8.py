@@ -9,8 +9,10 @@ The sources are copied to experiments/abl/src_i8/ and patched THERE (nsfnet_amd/
    element, what the real thing needs too), so that the E phases downstream keep seeing finite O(1) pseudo-random data
    (NaN or zero data would lower the power and flatter the variant: profiles/r03_ablations.txt D).
  * dw_bf16: the software pipeline's interleave is re-paced for half the MFMAs (the conversion VALU stays).
-NOT modelled: the extra VALU of quantising to limbs (row maxima, scaling, byte packing) in the E phases / the staging.
-Each library patches ONE kernel, so the other kernels see real data:  bash scripts/run_abl.sh bwd,dw base i8bwd i8dw"""
+NOT modelled in i8bwd / i8dw: the extra VALU of quantising to limbs (row maxima, scaling, byte packing) in the E phases /
+the staging.  i8dwq = i8dw plus 4 VALU per staged value in dW (what scaling, rounding, limb split and byte packing add to
+the bf16 split that stays in place as the stand-in of the limb-plane writes).
+Each library patches ONE kernel, so the other kernels see real data:  bash scripts/run_abl.sh bwd,dw base i8bwd i8dw i8dwq"""
 import os
 import shutil
 import subprocess
@@ -31,6 +33,19 @@ __device__ __forceinline__ f32x16 mfma_i8_standin(u32x4 a, u32x4 b, f32x16 c) {
 #define MFMA_Q(q, a, b, c) ((((q) & 1)) ? (c) : mfma_i8_standin(a, b, c))
 '''
 CONVERT = "  return (float)__builtin_bit_cast(int, acc_elem) * 2e-6f;\n#else"
+
+
+# +4 VALU per staged value (32 values per thread and chunk): scale, round to integer, split into two limbs, pack the bytes -
+# against the ~2.5 per value of the bf16 hi / lo split that stays in place (its image writes are the limb planes' stand-in)
+QUANT_VALU = '''
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        asm volatile("v_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0" : "+v"(zr[s][e]));
+        asm volatile("v_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0\\n\\tv_fma_f32 %0, %0, 1.0, 0" : "+v"(av[s][e]));
+      }
+'''
 
 
 def patch(path, old, new):
@@ -54,7 +69,15 @@ def main():
     patch(os.path.join(src, "dw_bf16.hip"), "constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1);",
           "constexpr int NMF = (DI::CH / 16) * TM * TN * (TERMS == 3 ? 3 : 1) / 2;")
     patch(os.path.join(src, "dw_bf16.hip"), "P24 ? 5 : 4, 0);", "P24 ? 10 : 8, 0);")
-    for name, victim in (("i8bwd", "bwd_bf16_split.hip"), ("i8dw", "dw_bf16.hip")):
+    srcq = os.path.join(out, "src_i8q")
+    shutil.rmtree(srcq, ignore_errors=True)
+    shutil.copytree(src, srcq)
+    patch(os.path.join(srcq, "dw_bf16.hip"), "    unsigned char* base = ldsb + (size_t)buf * 4 * DI::ARR + p * DI::RSB + (og ^ (p & 6)) * 8;", QUANT_VALU +
+          "    unsigned char* base = ldsb + (size_t)buf * 4 * DI::ARR + p * DI::RSB + (og ^ (p & 6)) * 8;")
+    patch(os.path.join(srcq, "dw_bf16.hip"), "P24 ? 10 : 8, 0);", "P24 ? 15 : 13, 0);")
+    for name, victim in (("i8bwd", "bwd_bf16_split.hip"), ("i8dw", "dw_bf16.hip"), ("i8dwq", "dw_bf16.hip")):
+        if name == "i8dwq":
+            src = srcq
         objs = []
         for s in B.SOURCES:
             o = os.path.join(B.OBJ, s.replace(".hip", ".o"))
